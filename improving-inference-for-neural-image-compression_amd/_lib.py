@@ -1,0 +1,111 @@
+"""ctypes binding of libsga_hip.so (C ABI: include/sga_hip.h).
+
+There is no CPU fallback: if the library is missing or no gfx950 device is visible the
+import of the product path fails loudly (`load_library` raises).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libsga_hip.so")
+
+SGA_ABI_VERSION = 1
+
+STATUS = {
+    0: "SGA_OK", -1: "SGA_ERR_BAD_ARG", -2: "SGA_ERR_BAD_SHAPE", -3: "SGA_ERR_UNSUPPORTED",
+    -4: "SGA_ERR_HIP", -5: "SGA_ERR_NO_DEVICE", -6: "SGA_ERR_NOMEM",
+}
+
+# sga_layer enum (include/sga_hip.h)
+LAYERS = {name: i for i, name in enumerate(
+    ["GA0", "GA1", "GA2", "GA3", "GS0", "GS1", "GS2", "GS3", "HA0", "HA1", "HA2", "HS0", "HS1", "HS2"])}
+
+
+class SgaConfig(C.Structure):
+    _fields_ = [("num_filters", C.c_int32), ("max_batch", C.c_int32), ("max_height", C.c_int32),
+                ("max_width", C.c_int32), ("bits_back", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+_FP = C.POINTER(C.c_float)
+
+
+class SgaWeights(C.Structure):
+    _fields_ = [
+        ("ga_kernel", _FP * 4), ("ga_bias", _FP * 4), ("ga_beta", _FP * 3), ("ga_gamma", _FP * 3),
+        ("gs_kernel", _FP * 4), ("gs_bias", _FP * 4), ("gs_beta", _FP * 3), ("gs_gamma", _FP * 3),
+        ("ha_kernel", _FP * 3), ("ha_bias", _FP * 3),
+        ("hs_kernel", _FP * 3), ("hs_bias", _FP * 3),
+        ("eb_matrix", _FP * 4), ("eb_bias", _FP * 4), ("eb_factor", _FP * 3),
+    ]
+
+
+# every symbol include/sga_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_F = C.c_float
+_I = C.c_int
+_I64 = C.c_int64
+SYMBOLS = {
+    "sga_abi_version": (_I, []),
+    "sga_create": (_I, [C.POINTER(_P), C.POINTER(SgaConfig), C.POINTER(SgaWeights)]),
+    "sga_destroy": (_I, [_P]),
+    "sga_last_error": (_I, [_P, C.c_char_p, _I]),
+    "sga_latent_shape": (_I, [_P, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "sga_encode": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "sga_step_grads": (_I, [_P, _P, _I, _I, _I, _P, _P, _F, _F, _F, C.c_uint64, C.c_uint32,
+                            _P, _P, _P, _P, _P, _P, _P]),
+    "sga_adam": (_I, [_P, _P, _P, _P, _P, _I64, _I, _F, _F, _F, _F, _P]),
+    "sga_run": (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _F, _F, _I, _F, C.c_uint64,
+                     _P, _P, _P, _P, _P, _P, _P]),
+    "sga_eval": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "sga_base_compress": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "sga_op_layer_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
+    "sga_op_layer_bwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P]),
+    "sga_op_sample": (_I, [_P, _P, _P, _I64, _F, _P, _P, _P]),
+    "sga_op_factorized_likelihood": (_I, [_P, _P, _I64, _P, _P, _P]),
+    "sga_op_gaussian_likelihood": (_I, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen libsga_hip.so and type every entry point.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} not found: the HIP extension is not built. Run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the SGA hot path.")
+    lib = C.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.sga_abi_version()
+    if ver != SGA_ABI_VERSION:
+        raise RuntimeError(f"libsga_hip ABI version {ver} != expected {SGA_ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class SgaError(RuntimeError):
+    pass
+
+
+def check(lib, handle, status: int, what: str):
+    if status == 0:
+        return
+    msg = STATUS.get(status, str(status))
+    detail = ""
+    if handle:
+        buf = C.create_string_buffer(256)
+        hip_err = lib.sga_last_error(handle, buf, 256)
+        if hip_err:
+            detail = f" (hipError {hip_err}: {buf.value.decode(errors='replace')})"
+    raise SgaError(f"{what} failed: {msg}{detail}")

@@ -1,0 +1,269 @@
+"""`SGACodec`: the host-side object behind which the reference's tf.Session interactions of
+sga.py sit.  PyTorch-ROCm tensors own the device memory and the stream;
+every arithmetic step is a call through the C ABI into libsga_hip.so.
+
+Reference interaction                                              -> method
+  tf.train.Saver().restore                     (sga.py:180-182)    -> SGACodec(weights, ...)
+  sess.run([y_init, z_init], {x})              (sga.py:207)        -> encode
+  sess.run([rd_gradients, rd_loss, ...])       (sga.py:212-214)    -> step_grads
+  Adam.update                                  (sga.py:215)        -> adam
+  the per-batch loop                           (sga.py:207-247)    -> run
+  sess.run(eval_tensors, {y_tilde:.., ..})     (sga.py:244-245)    -> evaluate
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import check_weights
+
+EVAL_FIELDS = ["mse", "psnr", "msssim", "msssim_db", "est_bpp", "est_y_bpp", "est_z_bpp"]  # sga.py:183
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class SGACodec:
+    def __init__(self, weights: dict, num_filters: int, max_batch: int, max_height: int,
+                 max_width: int, device: str | torch.device = "cuda:0", bits_back: bool = False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("SGACodec needs a ROCm GPU (gfx950); there is no CPU fallback")
+        self.lib = _lib.load_library()
+        self.device = torch.device(device)
+        self.C = int(num_filters)
+        self.bits_back = bool(bits_back)
+        check_weights(weights, self.C, bits_back)
+        self.max_batch, self.max_height, self.max_width = int(max_batch), int(max_height), int(max_width)
+        torch.cuda.set_device(self.device)
+        # a dedicated non-null stream: hipGraph capture is not allowed on the legacy null stream
+        self.stream = torch.cuda.Stream(device=self.device)
+        cfg = _lib.SgaConfig(self.C, self.max_batch, self.max_height, self.max_width, int(bits_back))
+        w = _lib.SgaWeights()
+        keep = []
+
+        def fp(name):
+            a = np.ascontiguousarray(weights[name], dtype=np.float32)
+            keep.append(a)
+            return a.ctypes.data_as(_lib._FP)
+
+        for i in range(4):
+            w.ga_kernel[i] = fp(f"ga.k{i}"); w.ga_bias[i] = fp(f"ga.b{i}")
+            w.gs_kernel[i] = fp(f"gs.k{i}"); w.gs_bias[i] = fp(f"gs.b{i}")
+            w.eb_matrix[i] = fp(f"eb.m{i}"); w.eb_bias[i] = fp(f"eb.b{i}")
+        for i in range(3):
+            w.ga_beta[i] = fp(f"ga.beta{i}"); w.ga_gamma[i] = fp(f"ga.gamma{i}")
+            w.gs_beta[i] = fp(f"gs.beta{i}"); w.gs_gamma[i] = fp(f"gs.gamma{i}")
+            w.ha_kernel[i] = fp(f"ha.k{i}"); w.hs_kernel[i] = fp(f"hs.k{i}")
+            w.hs_bias[i] = fp(f"hs.b{i}")
+            w.eb_factor[i] = fp(f"eb.f{i}")
+        w.ha_bias[0] = fp("ha.b0"); w.ha_bias[1] = fp("ha.b1")
+        self.handle = C.c_void_p(0)
+        st = self.lib.sga_create(C.byref(self.handle), C.byref(cfg), C.byref(w))
+        _lib.check(self.lib, None, st, "sga_create")
+        del keep
+
+    def close(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self.lib.sga_destroy(self.handle)
+            self.handle = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _t(self, a, shape=None):
+        t = torch.as_tensor(a, dtype=torch.float32, device=self.device).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def _empty(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _enter(self):
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def _exit(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def _chk(self, st, what):
+        _lib.check(self.lib, self.handle, st, what)
+
+    def latent_shape(self, H, W):
+        yh, yw, zh, zw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.lib.sga_latent_shape(self.handle, H, W, C.byref(yh), C.byref(yw),
+                                            C.byref(zh), C.byref(zw)), "sga_latent_shape")
+        return yh.value, yw.value, zh.value, zw.value
+
+    def _shapes(self, x):
+        B, H, W, c3 = x.shape
+        if c3 != 3:
+            raise ValueError("x must be [B,H,W,3]")
+        yh, yw, zh, zw = self.latent_shape(H, W)
+        zc = 2 * self.C if self.bits_back else self.C
+        return B, H, W, (B, yh, yw, self.C), (B, zh, zw, zc)
+
+    # ---- the session interactions ------------------------------------------------------------
+    def encode(self, x):
+        x = self._t(x)
+        B, H, W, ys, zs = self._shapes(x)
+        y, z = self._empty(*ys), self._empty(*zs)
+        s = self._enter()
+        self._chk(self.lib.sga_encode(self.handle, _ptr(x), B, H, W, _ptr(y), _ptr(z), s), "sga_encode")
+        self._exit()
+        return y, z
+
+    def step_grads(self, x, y, z, T, lmbda, loss_scale=None, seed=0, it=0, u_y=None, u_z=None):
+        x = self._t(x)
+        B, H, W, ys, zs = self._shapes(x)
+        y, z = self._t(y, ys), self._t(z, zs)
+        if loss_scale is None:
+            loss_scale = 1.0 / B
+        uy = self._t(u_y).reshape(*ys, 2) if u_y is not None else None
+        uz = self._t(u_z).reshape(*zs, 2) if u_z is not None else None
+        gy, gz = self._empty(*ys), self._empty(*zs)
+        scal, psnr = self._empty(3), self._empty(B)
+        s = self._enter()
+        self._chk(self.lib.sga_step_grads(self.handle, _ptr(x), B, H, W, _ptr(y), _ptr(z), float(T),
+                                          float(lmbda), float(loss_scale), int(seed), int(it),
+                                          _ptr(uy), _ptr(uz), _ptr(gy), _ptr(gz), _ptr(scal),
+                                          _ptr(psnr), s), "sga_step_grads")
+        self._exit()
+        sc = scal.cpu().numpy()
+        return dict(gy=gy, gz=gz, rd_loss=float(sc[0]), train_mse=float(sc[1]),
+                    train_bpp=float(sc[2]), psnr=psnr)
+
+    def adam(self, p, g, m, v, t, lr=0.005, beta_1=0.9, beta_2=0.999, epsilon=1e-8):
+        """In-place adam.py:20-59 update of one array (t = iterations + 1)."""
+        for a in (p, g, m, v):
+            if not (a.is_cuda and a.dtype == torch.float32 and a.is_contiguous()):
+                raise ValueError("adam operands must be contiguous float32 CUDA tensors")
+        s = self._enter()
+        self._chk(self.lib.sga_adam(self.handle, _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(),
+                                    int(t), lr, beta_1, beta_2, epsilon, s), "sga_adam")
+        self._exit()
+        return p
+
+    def run(self, x, lmbda, its=2000, lr=0.005, annealing_rate=1e-3, t0=700, T_ub=0.5, seed=0,
+            loss_scale=None, y0=None, z0=None, trace=False, metrics=True):
+        """sga.py:207-247 entirely on the device. Returns (y_hat, z_hat, metrics[B,7], trace)."""
+        x = self._t(x)
+        B, H, W, ys, zs = self._shapes(x)
+        if loss_scale is None:
+            loss_scale = 1.0 / B
+        y0t = self._t(y0, ys) if y0 is not None else None
+        z0t = self._t(z0, zs) if z0 is not None else None
+        y_hat, z_hat = self._empty(*ys), self._empty(*zs)
+        met = self._empty(B, 7) if metrics else None
+        tr = self._empty(max(its, 1), 4) if trace else None
+        s = self._enter()
+        self._chk(self.lib.sga_run(self.handle, _ptr(x), B, H, W, float(lmbda), float(loss_scale),
+                                   int(its), float(lr), float(annealing_rate), int(t0), float(T_ub),
+                                   int(seed), _ptr(y0t), _ptr(z0t), _ptr(y_hat), _ptr(z_hat),
+                                   _ptr(met), _ptr(tr), s), "sga_run")
+        self._exit()
+        return y_hat, z_hat, met, (tr[:its] if trace else None)
+
+    def evaluate(self, x, y_hat, z_hat, want_x_hat=False):
+        x = self._t(x)
+        B, H, W, ys, zs = self._shapes(x)
+        y_hat, z_hat = self._t(y_hat, ys), self._t(z_hat, zs)
+        met = self._empty(B, 7)
+        xh = self._empty(B, H, W, 3) if want_x_hat else None
+        s = self._enter()
+        self._chk(self.lib.sga_eval(self.handle, _ptr(x), B, H, W, _ptr(y_hat), _ptr(z_hat),
+                                    _ptr(met), _ptr(xh), s), "sga_eval")
+        self._exit()
+        return (met, xh) if want_x_hat else met
+
+    def base_compress(self, x, medians=None):
+        """mbt2018.py compress, estimated-rate path (cfg 1)."""
+        x = self._t(x)
+        B, H, W, ys, zs = self._shapes(x)
+        med = self._t(medians, (self.C,)) if medians is not None else None
+        y_hat, z_hat, met = self._empty(*ys), self._empty(*zs), self._empty(B, 7)
+        s = self._enter()
+        self._chk(self.lib.sga_base_compress(self.handle, _ptr(x), B, H, W, _ptr(med), _ptr(y_hat),
+                                             _ptr(z_hat), _ptr(met), s), "sga_base_compress")
+        self._exit()
+        return y_hat, z_hat, met
+
+    # ---- operator surface (unit parity) --------------------------------------------------------
+    def layer_fwd(self, layer: str, inp):
+        inp = self._t(inp)
+        B, Hi, Wi, Ci = inp.shape
+        C_, C15 = self.C, int(self.C * 1.5)
+        up = {"GS0": C_, "GS1": C_, "GS2": C_, "GS3": 3, "HS0": C_, "HS1": C15}
+        down = {"GA0": C_, "GA1": C_, "GA2": C_, "GA3": C_, "HA1": C_,
+                "HA2": 2 * C_ if self.bits_back else C_}
+        if layer in up:
+            out = self._empty(B, 2 * Hi, 2 * Wi, up[layer])
+        elif layer in down:
+            out = self._empty(B, (Hi + 1) // 2, (Wi + 1) // 2, down[layer])
+        elif layer == "HA0":
+            out = self._empty(B, Hi, Wi, C_)
+        elif layer == "HS2":
+            out = self._empty(B, Hi, Wi, 2 * C_)
+        else:
+            raise ValueError(layer)
+        s = self._enter()
+        self._chk(self.lib.sga_op_layer_fwd(self.handle, _lib.LAYERS[layer], _ptr(inp), B, Hi, Wi,
+                                            _ptr(out), s), f"sga_op_layer_fwd({layer})")
+        self._exit()
+        return out
+
+    def layer_bwd(self, layer: str, inp, g_out):
+        inp, g_out = self._t(inp), self._t(g_out)
+        B, Hi, Wi, Ci = inp.shape
+        g_in = torch.empty_like(inp)
+        s = self._enter()
+        self._chk(self.lib.sga_op_layer_bwd(self.handle, _lib.LAYERS[layer], _ptr(inp), _ptr(g_out),
+                                            B, Hi, Wi, _ptr(g_in), s), f"sga_op_layer_bwd({layer})")
+        self._exit()
+        return g_in
+
+    def sample(self, v, u, T):
+        v = self._t(v)
+        u = self._t(u).reshape(*v.shape, 2)
+        vt, jac = torch.empty_like(v), torch.empty_like(v)
+        s = self._enter()
+        self._chk(self.lib.sga_op_sample(self.handle, _ptr(v), _ptr(u), v.numel(), float(T),
+                                         _ptr(vt), _ptr(jac), s), "sga_op_sample")
+        self._exit()
+        return vt, jac
+
+    def factorized_likelihood(self, v):
+        v = self._t(v)
+        if v.shape[-1] != self.C:
+            raise ValueError("last dim must be num_filters")
+        p, dp = torch.empty_like(v), torch.empty_like(v)
+        s = self._enter()
+        self._chk(self.lib.sga_op_factorized_likelihood(self.handle, _ptr(v), v.numel() // self.C,
+                                                        _ptr(p), _ptr(dp), s),
+                  "sga_op_factorized_likelihood")
+        self._exit()
+        return p, dp
+
+    def gaussian_likelihood(self, y, mu, sigma_raw):
+        y, mu, sr = self._t(y), self._t(mu), self._t(sigma_raw)
+        outs = [torch.empty_like(y) for _ in range(4)]
+        s = self._enter()
+        self._chk(self.lib.sga_op_gaussian_likelihood(self.handle, _ptr(y), _ptr(mu), _ptr(sr),
+                                                      y.numel(), *[_ptr(o) for o in outs], s),
+                  "sga_op_gaussian_likelihood")
+        self._exit()
+        return tuple(outs)
+
+
+def metrics_to_dict(met) -> dict:
+    """[B,7] metrics tensor -> dict keyed like sga.py:183 eval_fields (numpy arrays)."""
+    m = met.detach().cpu().numpy()
+    return {k: m[:, i].copy() for i, k in enumerate(EVAL_FIELDS)}

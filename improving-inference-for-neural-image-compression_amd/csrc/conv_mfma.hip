@@ -1,0 +1,300 @@
+// Gather-GEMM convolution on the CDNA4 fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+// Every convolution on the SGA hot path -- the stride-2 5x5 convs of the analysis side,
+// the stride-2 transposed 5x5 convs of the synthesis side (as 4 sub-pixel phases), their
+// data-gradients, the 3x3 stride-1 convs, and the C x C channel contractions of GDN/IGDN
+// and their backward (tfc.SignalConv2D / tfc.GDN at nn_models.py:14-163) -- is one
+// implicit GEMM:
+//     M = output pixels of one sub-pixel phase,  N = output channels,  K = taps x C_in
+// with both operands stored K-major:
+//     A row = C_in contiguous floats of one NHWC input pixel (gathered per tap),
+//     B row = C_in contiguous floats of the pre-packed weight slab [tap][n][ci].
+// A workgroup owns a (BM x BN) output tile, BN = all (or a large slice of) the output
+// channels so that each gathered activation row is read once; K is walked in 32-wide
+// steps: global -> registers (prefetch of step k+1 overlaps the MFMAs of step k) ->
+// LDS [row][36] (pad 4: conflict-free ds_read_b128) -> per-lane float4 fragments that
+// feed four back-to-back 32x32x2 MFMAs each.
+//
+// f32 MFMA is a bitwise f32 fmaf chain (cdna_hip_programming.md s3), so results match an
+// f32 reference to summation-order rounding; no reduced precision anywhere.
+#include "sga_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BK = 32;   // K-step
+constexpr int LDK = 36;  // LDS row pitch in floats (BK + 4)
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+
+template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int RPP = NT / 8;                 // tile rows covered by one pass of the loaders
+  constexpr int PA = BM / RPP, PB = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
+  constexpr int PX = (PRO == PRO_IGDN_BWD) ? PA : 1;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + BM * LDK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int chunk = tid & 7, lrow = tid >> 3;
+
+  int bid = blockIdx.x;
+  const int nt = bid % a.ntiles_n;
+  bid /= a.ntiles_n;
+  const int phase = bid / a.tiles_per_phase;
+  const int mt = bid - phase * a.tiles_per_phase;
+  const ConvPhase ph = a.ph[phase];
+  const int Mtot = a.B * a.Hg * a.Wg;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- per-thread gather metadata for the PA rows this thread stages -----------------
+  int a_iy[PA], a_ix[PA], a_base[PA];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int m = m0 + p * RPP + lrow;
+    if (m < Mtot) {
+      const int j = m % a.Wg;
+      const int t = m / a.Wg;
+      const int i = t % a.Hg;
+      const int b = t / a.Hg;
+      a_iy[p] = i * a.s_in;
+      a_ix[p] = j * a.s_in;
+      a_base[p] = b * a.Hin * a.Win;
+    } else {
+      a_iy[p] = -(1 << 20);
+      a_ix[p] = 0;
+      a_base[p] = 0;
+    }
+  }
+
+  f32x4 ra[PA], rb[PB], ra1[PX], ra2[PX];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
+
+  auto gload = [&](int tapi, int ci0) {
+    const ConvTap tp = a.taps[ph.tap_begin + tapi];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      if constexpr (SMALLC) {
+        // `in` is a zero-padded 3-channel image; one K-step = two kernel rows (ky, ky+1),
+        // each 16 contiguous floats (5 taps x 3 channels + 1 float of slack, weight 0).
+        int ky = tp.dy + (chunk >> 2);
+        ky = ky > 4 ? 4 : ky;
+        const bool ok = a_iy[p] >= 0;
+        const size_t off =
+            ((size_t)(a_base[p] + (a_iy[p] + ky) * a.Win + a_ix[p])) * 3 + (chunk & 3) * 4;
+        f32x2 lo = {0.f, 0.f}, hi = {0.f, 0.f};
+        if (ok) {
+          lo = ld2(a.in + off);
+          hi = ld2(a.in + off + 2);
+        }
+        ra[p] = f32x4{lo.x, lo.y, hi.x, hi.y};
+      } else {
+        const int iy = a_iy[p] + tp.dy, ix = a_ix[p] + tp.dx;
+        const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        const size_t off =
+            (size_t)(a_base[p] + iy * a.Win + ix) * a.in_cs + a.in_coff + ci0 + chunk * 4;
+        ra[p] = ok ? ld4(a.in + off) : zero4;
+        if constexpr (PRO == PRO_IGDN_BWD) {
+          ra1[p] = ok ? ld4(a.aux1 + off) : one4;
+          ra2[p] = ok ? ld4(a.aux2 + off) : zero4;
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int n = n0 + p * RPP + lrow;
+      const size_t off = ((size_t)tp.slab * a.Npad + n) * a.Cin + ci0 + chunk * 4;
+      rb[p] = ld4(a.w + off);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int nsteps = ph.ntaps * (a.Cin / BK);
+  int tapi = 0, ci0 = 0;
+  gload(0, 0);
+
+  const int arow = (wm * TM) * 32 + (lane & 31);
+  const int brow = (wn * TN) * 32 + (lane & 31);
+  const int koff = (lane >> 5) * 4;
+
+  for (int ks = 0; ks < nsteps; ++ks) {
+    // ---- staged registers -> LDS (prologue transform fused here) ----------------------
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      f32x4 v = ra[p];
+      if constexpr (PRO == PRO_SQUARE) v = v * v;
+      if constexpr (PRO == PRO_IGDN_BWD) v = v * ra2[p] / ra1[p];   // g * u / s
+      *reinterpret_cast<f32x4*>(&As[(p * RPP + lrow) * LDK + chunk * 4]) = v;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+      *reinterpret_cast<f32x4*>(&Bs[(p * RPP + lrow) * LDK + chunk * 4]) = rb[p];
+    __syncthreads();
+
+    // ---- prefetch the next K-step while this one is multiplied ------------------------
+    ci0 += BK;
+    if (ci0 >= a.Cin) { ci0 = 0; ++tapi; }
+    if (ks + 1 < nsteps) gload(tapi, ci0);
+
+    // ---- 32 k's = 4 x (float4 fragment -> 4 MFMAs per output sub-tile) -----------------
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        af[tm] = *reinterpret_cast<const f32x4*>(&As[(arow + tm * 32) * LDK + q * 8 + koff]);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        bf[tn] = *reinterpret_cast<const f32x4*>(&Bs[(brow + tn * 32) * LDK + q * 8 + koff]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] =
+                __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][r], bf[tn][r], acc[tm][tn], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)
+  const int half = lane >> 5, col = lane & 31;
+  const int epi = a.epi;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+      const int m = m0 + (wm * TM + tm) * 32 + row;
+      if (m >= Mtot) continue;
+      const int j = m % a.Wg;
+      const int t = m / a.Wg;
+      const int i = t % a.Hg;
+      const int b = t / a.Hg;
+      if (epi == EPI_SHUFFLE3) {
+        // columns n = (py*2+px)*3 + c of a combined-phase C->3 transposed conv
+        if (TN == 1 && wn == 0) {
+          const int n = n0 + col;
+          if (n < 12) {
+            const int pp = n / 3, c = n - pp * 3;
+            const int oy = 2 * i + (pp >> 1), ox = 2 * j + (pp & 1);
+            if (oy < a.Hout && ox < a.Wout)
+              a.out[((size_t)(b * a.Hout + oy) * a.Wout + ox) * 3 + c] =
+                  acc[tm][0][reg] + (a.bias ? a.bias[c] : 0.f);
+          }
+        }
+        continue;
+      }
+      const int oy = i * a.s_out + ph.py, ox = j * a.s_out + ph.px;
+      if (oy >= a.Hout || ox >= a.Wout) continue;
+      const size_t obase = ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.out_cs + a.out_coff;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + (wn * TN + tn) * 32 + col;
+        if (n >= a.Cout) continue;
+        float v = acc[tm][tn][reg];
+        const size_t o = obase + n;
+        switch (epi) {
+          case EPI_BIAS:
+            if (a.bias) v += a.bias[n];
+            break;
+          case EPI_BIAS_RELU:
+            if (a.bias) v += a.bias[n];
+            v = fmaxf(v, 0.f);
+            break;
+          case EPI_IGDN: {
+            const float s = sqrtf(v + a.bias[n]);
+            a.aux_out[o] = s;
+            v = a.aux0[o] * s;
+          } break;
+          case EPI_GDN:
+            v = a.aux0[o] / sqrtf(v + a.bias[n]);
+            break;
+          case EPI_IGDN_BWD:
+            v = a.in[o] * a.aux1[o] + a.aux2[o] * v;
+            break;
+          case EPI_RELU_MASK:
+            v = a.aux0[o] > 0.f ? v : 0.f;
+            break;
+          default:
+            break;
+        }
+        a.out[o] = v;
+      }
+    }
+  }
+}
+
+template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC>
+int launch_inst(const ConvArgs& a, hipStream_t stream) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const size_t lds = (size_t)(BM + BN) * LDK * sizeof(float);
+  const int grid = a.nphase * a.tiles_per_phase * a.ntiles_n;
+  if (grid <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC>), dim3(grid), dim3(NT), lds,
+                     stream, a);
+  return (int)hipGetLastError();
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_pro(const ConvArgs& a, hipStream_t s) {
+  if (a.smallc) return launch_inst<TM, TN, WM, WN, PRO_NONE, true>(a, s);
+  switch (a.pro) {
+    case PRO_NONE: return launch_inst<TM, TN, WM, WN, PRO_NONE, false>(a, s);
+    case PRO_SQUARE: return launch_inst<TM, TN, WM, WN, PRO_SQUARE, false>(a, s);
+    case PRO_IGDN_BWD: return launch_inst<TM, TN, WM, WN, PRO_IGDN_BWD, false>(a, s);
+  }
+  return (int)hipErrorInvalidValue;
+}
+
+}  // namespace
+
+int conv_pick_bn(int cout, int epi) {
+  if (epi == EPI_SHUFFLE3) return 32;
+  const int cand[4] = {256, 192, 96, 64};
+  int best = 0, best_cost = 1 << 30;
+  for (int k = 0; k < 4; ++k) {
+    const int bn = cand[k];
+    const int cost = (cout + bn - 1) / bn * bn;
+    if (cost < best_cost) { best_cost = cost; best = bn; }   // ties keep the larger (earlier) BN
+  }
+  return best;
+}
+
+int conv_tile_m(int bn) { (void)bn; return 128; }
+
+int launch_conv(const ConvArgs& a, hipStream_t stream) {
+  const int bn = a.Npad / a.ntiles_n;
+  switch (bn) {
+    case 192: return launch_pro<2, 3, 2, 2>(a, stream);
+    case 256: return launch_pro<2, 4, 2, 2>(a, stream);
+    case 64: return launch_pro<2, 1, 2, 2>(a, stream);
+    case 96:
+      if (a.smallc || a.pro != PRO_NONE) return (int)hipErrorInvalidValue;
+      return launch_inst<2, 3, 2, 1, PRO_NONE, false>(a, stream);
+    case 32:
+      if (a.smallc || a.pro != PRO_NONE) return (int)hipErrorInvalidValue;
+      return launch_inst<1, 1, 4, 1, PRO_NONE, false>(a, stream);
+  }
+  return (int)hipErrorInvalidValue;
+}

@@ -1,0 +1,603 @@
+// HBM-bound kernels of the SGA step: the Gumbel-softmax floor/ceil relaxation, both entropy
+// models with their analytic gradients, the distortion, the fused chain-rule + Adam update and
+// the per-image reductions.  Each is a single coalesced pass over a latent- or image-sized
+// array (<= a few MB per image-step, SURVEY.md 8(d) "algorithmic bytes"); the arithmetic the
+// reference expresses as TF graph ops + tf.gradients (sga.py:86-164) is written out in closed
+// form here.  Compiled with -ffp-contract=off so the f32 arithmetic matches an unfused
+// restatement (Adam is bit-exact vs. the f32-pinned adam.py restatement).
+#include "kernels.h"
+
+namespace {
+
+constexpr float kEps = 1e-5f;          // sga.py:30
+constexpr float kLikBound = 1e-9f;     // sga.py:28 / tfc likelihood_bound
+constexpr float kScaleMin = 0.11f;     // sga.py:24
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+constexpr float kInvSqrt2Pi = 0.3989422804014327f;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sum of up to 4 doubles; result valid in thread 0
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double* sh /* [N][16] */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    v[k] = wave_sum(v[k]);
+    if (lane == 0) sh[k * 16 + wid] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      double s = 0.0;
+      for (int w = 0; w < nw; ++w) s += sh[k * 16 + w];
+      v[k] = s;
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoidf(float t) { return 1.0f / (1.0f + expf(-t)); }
+__device__ __forceinline__ float sgnf(float t) { return (t > 0.f) - (t < 0.f); }
+
+// ------------------------------------------------------------------------------------------
+// SGA relaxation (sga.py:86-98 for z, :111-121 for y) + its Jacobian d v_tilde / d v.
+//   logits = [-atanh(clip(v-floor)) / T, -atanh(clip(ceil-v)) / T]
+//   s = softmax((logits + gumbel) / T)          (tfp RelaxedOneHotCategorical.sample)
+//   v_tilde = floor*s0 + ceil*s1
+// floor/ceil carry no gradient; clip passes gradient inside [-1+eps, 1-eps].
+// ------------------------------------------------------------------------------------------
+__global__ void k_sample(const float* __restrict__ v, const float* __restrict__ u,
+                         const StepCtx* __restrict__ ctx, int stream_id, float* __restrict__ vt,
+                         float* __restrict__ dvt, int64_t n) {
+  const float T = ctx->T;
+  const int it = ctx->it;
+  const unsigned k0 = ctx->seed_lo, k1 = ctx->seed_hi;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    float u0, u1;
+    if (u) {
+      u0 = u[2 * idx];
+      u1 = u[2 * idx + 1];
+    } else {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)idx, (uint32_t)((uint64_t)idx >> 32), (uint32_t)it,
+                    (uint32_t)stream_id, k0, k1, r);
+      u0 = bits_to_uniform(r[0]);
+      u1 = bits_to_uniform(r[1]);
+    }
+    const float x = v[idx];
+    const float fl = floorf(x), ce = ceilf(x);
+    const float rdn = x - fl, rup = ce - x;
+    const float lo = -1.0f + kEps, hi = 1.0f - kEps;
+    const float ddn = fminf(fmaxf(rdn, lo), hi);
+    const float dup = fminf(fmaxf(rup, lo), hi);
+    const float ldn = -atanhf(ddn) / T;
+    const float lup = -atanhf(dup) / T;
+    const float g0 = -logf(-logf(u0));
+    const float g1 = -logf(-logf(u1));
+    const float a0 = (ldn + g0) / T, a1 = (lup + g1) / T;
+    const float mx = fmaxf(a0, a1);
+    const float e0 = expf(a0 - mx), e1 = expf(a1 - mx);
+    const float den = e0 + e1;
+    const float s0 = e0 / den, s1 = e1 / den;
+    vt[idx] = fl * s0 + ce * s1;
+    if (dvt) {
+      const float mdn = (rdn >= lo && rdn <= hi) ? 1.0f : 0.0f;
+      const float mup = (rup >= lo && rup <= hi) ? 1.0f : 0.0f;
+      // d(a1 - a0)/dv = (1/T^2) * ( mup/(1-dup^2) + mdn/(1-ddn^2) )
+      const float dd = (mup / (1.0f - dup * dup) + mdn / (1.0f - ddn * ddn)) / (T * T);
+      dvt[idx] = (ce - fl) * s0 * s1 * dd;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Factorized prior: per-channel monotone 1->3->3->3->1 network giving the CDF logit
+// (learned_prior.py:96-121) and its derivative w.r.t. the input (forward mode).
+// Packed per channel (EB_STRIDE floats): m0[3] b0[3] f0[3] m1[9] b1[3] f1[3] m2[9] b2[3] f2[3] m3[3] b3
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void eb_logit(const float* __restrict__ P, float x, float& out,
+                                         float& dout) {
+  float h[3], d[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    h[r] = P[r] * x + P[3 + r];
+    d[r] = P[r];
+    const float t = tanhf(h[r]);
+    const float f = P[6 + r];
+    h[r] += f * t;
+    d[r] *= 1.0f + f * (1.0f - t * t);
+  }
+#pragma unroll
+  for (int layer = 0; layer < 2; ++layer) {
+    const float* M = P + 9 + layer * 15;
+    float h2[3], d2[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float acc = 0.f, dacc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        acc += M[r * 3 + c] * h[c];
+        dacc += M[r * 3 + c] * d[c];
+      }
+      acc += M[9 + r];
+      const float t = tanhf(acc);
+      const float f = M[12 + r];
+      h2[r] = acc + f * t;
+      d2[r] = dacc * (1.0f + f * (1.0f - t * t));
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { h[r] = h2[r]; d[r] = d2[r]; }
+  }
+  const float* M3 = P + 39;
+  float acc = 0.f, dacc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    acc += M3[c] * h[c];
+    dacc += M3[c] * d[c];
+  }
+  out = acc + M3[3];
+  dout = dacc;
+}
+
+// tfc EntropyBottleneck._likelihood (sga.py:101): box mass with the sign trick, and dp/dv
+__device__ __forceinline__ void eb_mass(const float* __restrict__ P, float x, float& p,
+                                        float& dp) {
+  float lo, dlo, up, dup_;
+  eb_logit(P, x - 0.5f, lo, dlo);
+  eb_logit(P, x + 0.5f, up, dup_);
+  const float sg = -sgnf(lo + up);
+  const float su = sigmoidf(sg * up), sl = sigmoidf(sg * lo);
+  const float diff = su - sl;
+  p = fabsf(diff);
+  dp = sgnf(diff) * sg * (su * (1.0f - su) * dup_ - sl * (1.0f - sl) * dlo);
+}
+
+// math_ops.py:63-76: gradient of lower_bound passes if x >= bound or the gradient is negative
+__device__ __forceinline__ float lower_bound_grad(float x, float bound, float g) {
+  return (x >= bound || g < 0.f) ? g : 0.f;
+}
+
+__global__ void k_factorized(const float* __restrict__ zt, const float* __restrict__ ebp,
+                             const StepCtx* __restrict__ ctx, int n_per_img, int C,
+                             float inv_ln2_hw, ImgSums* __restrict__ sums,
+                             float* __restrict__ g_zt, float* __restrict__ p_out,
+                             float* __restrict__ dp_out) {
+  __shared__ double sh[16];
+  const int b = blockIdx.y;
+  const float ls = ctx ? ctx->loss_scale : 1.0f;
+  double nats[1] = {0.0};
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_per_img; e += gridDim.x * blockDim.x) {
+    const size_t idx = (size_t)b * n_per_img + e;
+    const int c = e % C;
+    float p, dp;
+    eb_mass(ebp + (size_t)c * EB_STRIDE, zt[idx], p, dp);
+    if (p_out) p_out[idx] = p;
+    if (dp_out) dp_out[idx] = dp;
+    const float pb = fmaxf(p, kLikBound);
+    nats[0] += (double)(-logf(pb));
+    if (g_zt) {
+      // d rd_loss / d p_bounded = -loss_scale / (ln2 * HW * p_bounded)
+      const float gp = lower_bound_grad(p, kLikBound, -ls * inv_ln2_hw / pb);
+      g_zt[idx] = gp * dp;
+    }
+  }
+  block_sum<1>(nats, sh);
+  if (threadIdx.x == 0 && sums) atomicAdd(&sums[b].z_nats, nats[0]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Gaussian conditional, box-convolved (utils.py:80-102 == tfc GaussianConditional._likelihood):
+//   sigma = max(exp(sraw), 0.11);  v = |y - mu|
+//   p = Phi((.5 - v)/sigma) - Phi((-.5 - v)/sigma),  Phi(t) = erfc(-t/sqrt2)/2
+// ------------------------------------------------------------------------------------------
+struct GaussOut { float p, dp_dy, dp_dmu, dp_dsig_b, sigma; };
+
+__device__ __forceinline__ GaussOut gauss_mass(float y, float mu, float sraw) {
+  GaussOut o;
+  const float sigma = expf(sraw);
+  const float sb = fmaxf(sigma, kScaleMin);
+  const float d = y - mu;
+  const float v = fabsf(d);
+  const float up = (0.5f - v) / sb, lo = (-0.5f - v) / sb;
+  const float cu = 0.5f * erfcf(-kInvSqrt2 * up);
+  const float cl = 0.5f * erfcf(-kInvSqrt2 * lo);
+  o.p = cu - cl;
+  const float phu = kInvSqrt2Pi * expf(-0.5f * up * up);
+  const float phl = kInvSqrt2Pi * expf(-0.5f * lo * lo);
+  const float dp_dv = (phl - phu) / sb;
+  const float sg = sgnf(d);
+  o.dp_dy = sg * dp_dv;
+  o.dp_dmu = -sg * dp_dv;
+  o.dp_dsig_b = (phl * lo - phu * up) / sb;
+  o.sigma = sigma;
+  return o;
+}
+
+__global__ void k_gaussian(const float* __restrict__ yt, const float* __restrict__ ms,
+                           const StepCtx* __restrict__ ctx, int h, int w, int hs, int ws, int C,
+                           float inv_ln2_hw, ImgSums* __restrict__ sums,
+                           float* __restrict__ g_yt, float* __restrict__ g_ms) {
+  __shared__ double sh[16];
+  const int b = blockIdx.y;
+  const float ls = ctx->loss_scale;
+  const int n_per_img = hs * ws * C;
+  double nats[1] = {0.0};
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_per_img; e += gridDim.x * blockDim.x) {
+    const int c = e % C;
+    const int pix = e / C;
+    const int j = pix % ws, i = pix / ws;
+    const size_t mo = ((size_t)(b * hs + i) * ws + j) * (2 * C) + c;
+    if (i < h && j < w) {
+      const size_t yo = ((size_t)(b * h + i) * w + j) * C + c;
+      const GaussOut o = gauss_mass(yt[yo], ms[mo], ms[mo + C]);
+      const float pb = fmaxf(o.p, kLikBound);
+      nats[0] += (double)(-logf(pb));
+      const float gp = lower_bound_grad(o.p, kLikBound, -ls * inv_ln2_hw / pb);
+      if (g_yt) g_yt[yo] = gp * o.dp_dy;
+      if (g_ms) {
+        g_ms[mo] = gp * o.dp_dmu;
+        const float gsb = lower_bound_grad(o.sigma, kScaleMin, gp * o.dp_dsig_b);
+        g_ms[mo + C] = gsb * o.sigma;       // d sigma / d sraw = sigma
+      }
+    } else if (g_ms) {
+      g_ms[mo] = 0.f;
+      g_ms[mo + C] = 0.f;
+    }
+  }
+  block_sum<1>(nats, sh);
+  if (threadIdx.x == 0) atomicAdd(&sums[b].y_nats, nats[0]);
+}
+
+__global__ void k_gaussian_op(const float* __restrict__ y, const float* __restrict__ mu,
+                              const float* __restrict__ sraw, int64_t n, float* __restrict__ p,
+                              float* __restrict__ dy, float* __restrict__ dmu,
+                              float* __restrict__ dsr) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const GaussOut o = gauss_mass(y[i], mu[i], sraw[i]);
+    if (p) p[i] = o.p;
+    if (dy) dy[i] = o.dp_dy;
+    if (dmu) dmu[i] = o.dp_dmu;
+    // unit form: straight derivative of max(exp(sraw), bound) (no upstream sign available)
+    if (dsr) dsr[i] = (o.sigma >= kScaleMin) ? o.dp_dsig_b * o.sigma : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Distortion (sga.py:150-154, 170-174)
+// ------------------------------------------------------------------------------------------
+__global__ void k_mse(const float* __restrict__ x, const float* __restrict__ xt,
+                      const StepCtx* __restrict__ ctx, int H, int W, int Hp, int Wp,
+                      ImgSums* __restrict__ sums, float* __restrict__ gpad,
+                      float* __restrict__ xq_out) {
+  __shared__ double sh[32];
+  const int b = blockIdx.y;
+  const int n_per_img = H * W * 3;
+  float coef = 0.f;
+  if (ctx && ctx->lambda > 0.f)
+    coef = ctx->lambda * 2.0f * 65025.0f * ctx->loss_scale / (float)n_per_img;
+  double acc[2] = {0.0, 0.0};
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_per_img; e += gridDim.x * blockDim.x) {
+    const size_t idx = (size_t)b * n_per_img + e;
+    const float xv = x[idx], tv = xt[idx];
+    const float d = xv - tv;
+    acc[0] += (double)(d * d);
+    const float q = rintf(fminf(fmaxf(tv, 0.f), 1.f) * 255.0f);
+    if (xq_out) xq_out[idx] = q;
+    const float dq = xv * 255.0f - q;
+    acc[1] += (double)(dq * dq);
+    if (gpad) {
+      const int c = e % 3;
+      const int pix = e / 3;
+      const int j = pix % W, i = pix / W;
+      gpad[((size_t)(b * Hp + i + 2) * Wp + j + 2) * 3 + c] = coef * (tv - xv);
+    }
+  }
+  block_sum<2>(acc, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[b].sq, acc[0]);
+    atomicAdd(&sums[b].sq_q, acc[1]);
+  }
+}
+
+__global__ void k_pad_image(const float* __restrict__ x, int H, int W, int Hp, int Wp,
+                            float* __restrict__ xp) {
+  const int b = blockIdx.y;
+  const int n = H * W * 3;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int c = e % 3, pix = e / 3;
+    const int j = pix % W, i = pix / W;
+    xp[((size_t)(b * Hp + i + 2) * Wp + j + 2) * 3 + c] = x[(size_t)b * n + e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// chain rule through the sampler + Adam (adam.py:40-56), float32 as numpy 1.17 computed it
+// ------------------------------------------------------------------------------------------
+__global__ void k_combine(const float* __restrict__ ga, const float* __restrict__ gb,
+                          const float* __restrict__ jac, float* __restrict__ g, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float s = ga[i];
+    if (gb) s += gb[i];
+    g[i] = s * jac[i];
+  }
+}
+
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float lr_t,
+                                            float b1, float omb1, float b2, float omb2,
+                                            float eps) {
+  const float m_t = (b1 * m) + omb1 * g;
+  const float v_t = (b2 * v) + omb2 * (g * g);
+  p = p - lr_t * m_t / (sqrtf(v_t) + eps);
+  m = m_t;
+  v = v_t;
+}
+
+__global__ void k_adam_latent(float* __restrict__ p, const float* __restrict__ ga,
+                              const float* __restrict__ gb, const float* __restrict__ jac,
+                              float* __restrict__ m, float* __restrict__ v, int64_t n,
+                              const StepCtx* __restrict__ ctx) {
+  const float lr_t = ctx->lr_t;
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+  const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float s = ga[i];
+    if (gb) s += gb[i];
+    const float g = s * jac[i];
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam_update(pp, g, mm, vv, lr_t, b1, omb1, b2, omb2, eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, int64_t n, float lr_t, float b1, float omb1,
+                       float b2, float omb2, float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam_update(pp, g[i], mm, vv, lr_t, b1, omb1, b2, omb2, eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+
+__global__ void k_set_ctx(StepCtx* ctx, int it, int its, float T, float lr_t, float lambda,
+                          float loss_scale, unsigned s_lo, unsigned s_hi) {
+  ctx->it = it; ctx->its = its; ctx->T = T; ctx->lr_t = lr_t; ctx->lambda = lambda;
+  ctx->loss_scale = loss_scale; ctx->seed_lo = s_lo; ctx->seed_hi = s_hi;
+}
+
+__global__ void k_advance_ctx(StepCtx* ctx, const float* __restrict__ Ttab,
+                              const float* __restrict__ lrtab) {
+  const int it = ctx->it + 1;
+  ctx->it = it;
+  ctx->T = Ttab[it];
+  ctx->lr_t = lrtab[it];
+}
+
+__global__ void k_finalize_step(ImgSums* sums, const StepCtx* __restrict__ ctx, int B, int H,
+                                int W, float* scalars, float* psnr, float* trace) {
+  if (threadIdx.x != 0) return;
+  const double npx = (double)H * W;
+  const double ls = ctx->loss_scale;
+  double sq = 0.0, nats = 0.0, ps = 0.0;
+  for (int b = 0; b < B; ++b) {
+    sq += sums[b].sq;
+    nats += sums[b].y_nats + sums[b].z_nats;
+    const double mse_q = sums[b].sq_q / (npx * 3.0);
+    const float pb = (float)(10.0 * log10(65025.0 / mse_q));
+    if (psnr) psnr[b] = pb;
+    ps += pb;
+    sums[b].sq = 0.0; sums[b].sq_q = 0.0; sums[b].y_nats = 0.0; sums[b].z_nats = 0.0;
+  }
+  const float train_mse = (float)(sq * ls / (npx * 3.0) * 65025.0);
+  const float train_bpp = (float)(nats * ls / (0.6931471805599453 * npx));
+  const float lam = ctx->lambda;
+  const float loss = lam > 0.f ? lam * train_mse + train_bpp : train_bpp;
+  if (scalars) { scalars[0] = loss; scalars[1] = train_mse; scalars[2] = train_bpp; }
+  if (trace) {
+    float* row = trace + (size_t)ctx->it * 4;
+    row[0] = loss; row[1] = train_mse; row[2] = train_bpp; row[3] = (float)(ps / B);
+  }
+}
+
+__global__ void k_finalize_eval(ImgSums* sums, int B, int H, int W, float* metrics) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double npx = (double)H * W;
+  const double mse = sums[b].sq_q / (npx * 3.0);
+  const double ybpp = sums[b].y_nats / (0.6931471805599453 * npx);
+  const double zbpp = sums[b].z_nats / (0.6931471805599453 * npx);
+  float* m = metrics + (size_t)b * 7;
+  m[0] = (float)mse;
+  m[1] = (float)(10.0 * log10(65025.0 / mse));
+  m[2] = __builtin_nanf("");      // msssim: filled by the MS-SSIM stage when enabled
+  m[3] = __builtin_nanf("");
+  m[4] = (float)(ybpp + zbpp);
+  m[5] = (float)ybpp;
+  m[6] = (float)zbpp;
+  sums[b].sq = 0.0; sums[b].sq_q = 0.0; sums[b].y_nats = 0.0; sums[b].z_nats = 0.0;
+}
+
+__global__ void k_round(const float* __restrict__ v, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = rintf(v[i]);      // round-half-to-even == np.round (sga.py:240-241)
+}
+
+__global__ void k_round_centered(const float* __restrict__ y, const float* __restrict__ ms, int B,
+                                 int h, int w, int hs, int ws, int C, float* __restrict__ out) {
+  const int64_t n = (int64_t)B * h * w * C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    int64_t pix = e / C;
+    const int j = (int)(pix % w); pix /= w;
+    const int i = (int)(pix % h);
+    const int b = (int)(pix / h);
+    const float mu = ms[((size_t)(b * hs + i) * ws + j) * (2 * C) + c];
+    out[e] = rintf(y[e] - mu) + mu;
+  }
+}
+
+__global__ void k_round_median(const float* __restrict__ z, const float* __restrict__ med,
+                               int64_t n, int C, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float m = med ? med[i % C] : 0.f;
+    out[i] = rintf(z[i] - m) + m;
+  }
+}
+
+__global__ void k_fill(float* __restrict__ p, float val, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = val;
+}
+
+__global__ void k_relu_mask(const float* __restrict__ g, const float* __restrict__ act,
+                            float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = act[i] > 0.f ? g[i] : 0.f;
+}
+
+inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+#define LAUNCH_RET() return (int)hipGetLastError()
+
+int launch_sample(const float* v, const float* u, const StepCtx* ctx, int stream_id, float* vt,
+                  float* dvt, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_sample, dim3(grid_for(n)), dim3(256), 0, s, v, u, ctx, stream_id, vt, dvt, n);
+  LAUNCH_RET();
+}
+
+int launch_factorized(const float* zt, const float* eb_packed, const StepCtx* ctx, int B, int npix,
+                      int C, float inv_ln2_hw, ImgSums* sums, float* g_zt, float* p_out,
+                      float* dp_out, hipStream_t s) {
+  const int n_per_img = npix * C;
+  hipLaunchKernelGGL(k_factorized, dim3(grid_for(n_per_img, 256, 256), B), dim3(256), 0, s, zt,
+                     eb_packed, ctx, n_per_img, C, inv_ln2_hw, sums, g_zt, p_out, dp_out);
+  LAUNCH_RET();
+}
+
+int launch_gaussian(const float* yt, const float* ms, const StepCtx* ctx, int B, int h, int w,
+                    int hs, int ws, int C, float inv_ln2_hw, ImgSums* sums, float* g_yt,
+                    float* g_ms, hipStream_t s) {
+  const int n_per_img = hs * ws * C;
+  hipLaunchKernelGGL(k_gaussian, dim3(grid_for(n_per_img, 256, 512), B), dim3(256), 0, s, yt, ms,
+                     ctx, h, w, hs, ws, C, inv_ln2_hw, sums, g_yt, g_ms);
+  LAUNCH_RET();
+}
+
+int launch_gaussian_op(const float* y, const float* mu, const float* sraw, int64_t n, float* p,
+                       float* dp_dy, float* dp_dmu, float* dp_dsraw, hipStream_t s) {
+  hipLaunchKernelGGL(k_gaussian_op, dim3(grid_for(n)), dim3(256), 0, s, y, mu, sraw, n, p, dp_dy,
+                     dp_dmu, dp_dsraw);
+  LAUNCH_RET();
+}
+
+int launch_mse(const float* x, const float* xt, const StepCtx* ctx, int B, int H, int W, int Hp,
+               int Wp, ImgSums* sums, float* gpad, float* xq_out, hipStream_t s) {
+  const int n_per_img = H * W * 3;
+  hipLaunchKernelGGL(k_mse, dim3(grid_for(n_per_img, 256, 512), B), dim3(256), 0, s, x, xt, ctx, H,
+                     W, Hp, Wp, sums, gpad, xq_out);
+  LAUNCH_RET();
+}
+
+int launch_pad_image(const float* x, int B, int H, int W, int Hp, int Wp, float* xp,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(k_pad_image, dim3(grid_for((int64_t)H * W * 3, 256, 512), B), dim3(256), 0, s,
+                     x, H, W, Hp, Wp, xp);
+  LAUNCH_RET();
+}
+
+int launch_combine_grad(const float* ga, const float* gb, const float* jac, float* g, int64_t n,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(k_combine, dim3(grid_for(n)), dim3(256), 0, s, ga, gb, jac, g, n);
+  LAUNCH_RET();
+}
+
+int launch_adam_latent(float* p, const float* ga, const float* gb, const float* jac, float* m,
+                       float* v, int64_t n, const StepCtx* ctx, hipStream_t s) {
+  hipLaunchKernelGGL(k_adam_latent, dim3(grid_for(n)), dim3(256), 0, s, p, ga, gb, jac, m, v, n,
+                     ctx);
+  LAUNCH_RET();
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1,
+                float b2, float eps, hipStream_t s) {
+  // adam.py:44-45: (1. - beta) is formed in double, then cast to the array dtype (float32)
+  const float omb1 = (float)(1.0 - (double)b1), omb2 = (float)(1.0 - (double)b2);
+  hipLaunchKernelGGL(k_adam, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, omb1, b2,
+                     omb2, eps);
+  LAUNCH_RET();
+}
+
+int launch_set_ctx(StepCtx* ctx, int it, int its, float T, float lr_t, float lambda,
+                   float loss_scale, uint64_t seed, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_ctx, dim3(1), dim3(1), 0, s, ctx, it, its, T, lr_t, lambda, loss_scale,
+                     (unsigned)(seed & 0xFFFFFFFFu), (unsigned)(seed >> 32));
+  LAUNCH_RET();
+}
+
+int launch_advance_ctx(StepCtx* ctx, const float* Ttab, const float* lrtab, hipStream_t s) {
+  hipLaunchKernelGGL(k_advance_ctx, dim3(1), dim3(1), 0, s, ctx, Ttab, lrtab);
+  LAUNCH_RET();
+}
+
+int launch_finalize_step(ImgSums* sums, const StepCtx* ctx, int B, int H, int W, float* scalars,
+                         float* psnr, float* trace, hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize_step, dim3(1), dim3(64), 0, s, sums, ctx, B, H, W, scalars, psnr,
+                     trace);
+  LAUNCH_RET();
+}
+
+int launch_finalize_eval(ImgSums* sums, int B, int H, int W, float* metrics, hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize_eval, dim3((B + 63) / 64), dim3(64), 0, s, sums, B, H, W, metrics);
+  LAUNCH_RET();
+}
+
+int launch_round(const float* v, float* out, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_round, dim3(grid_for(n)), dim3(256), 0, s, v, out, n);
+  LAUNCH_RET();
+}
+
+int launch_round_centered(const float* y, const float* ms, int B, int h, int w, int hs, int ws,
+                          int C, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_round_centered, dim3(grid_for((int64_t)B * h * w * C)), dim3(256), 0, s, y,
+                     ms, B, h, w, hs, ws, C, out);
+  LAUNCH_RET();
+}
+
+int launch_round_median(const float* z, const float* med, int64_t n, int C, float* out,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(k_round_median, dim3(grid_for(n)), dim3(256), 0, s, z, med, n, C, out);
+  LAUNCH_RET();
+}
+
+int launch_fill(float* p, float val, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(256), 0, s, p, val, n);
+  LAUNCH_RET();
+}
+
+int launch_relu_mask(const float* g, const float* act, float* out, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_relu_mask, dim3(grid_for(n)), dim3(256), 0, s, g, act, out, n);
+  LAUNCH_RET();
+}

@@ -1,0 +1,75 @@
+// Host-callable launchers of the elementwise / entropy-model / reduction kernels
+// (elementwise.hip).  All pointers are device memory; every launcher returns hipError_t.
+#pragma once
+#include "sga_common.h"
+
+constexpr int EB_STRIDE = 44;   // packed floats per channel of the factorized prior
+
+// per-image accumulators (double), zeroed by k_finalize after being consumed
+struct ImgSums {
+  double sq;      // sum (x - x_tilde)^2                       sga.py:150
+  double sq_q;    // sum (255x - round(255 clip(x_tilde)))^2   sga.py:170-173
+  double y_nats;  // sum -ln p(y_tilde | z_tilde)              sga.py:144
+  double z_nats;  // sum -ln p(z_tilde)                        sga.py:145
+};
+
+// SGA relaxation sga.py:86-98 / :111-121 (+ tfp RelaxedOneHotCategorical.sample).
+// u != null: injected uniforms [n][2]; else Philox keyed by ctx (stream_id 0 = y, 1 = z).
+int launch_sample(const float* v, const float* u, const StepCtx* ctx, int stream_id,
+                  float* vt, float* dvt, int64_t n, hipStream_t s);
+
+// Factorized prior on z_tilde [B, npix, C]: accumulates -ln p into sums[b].z_nats and writes
+// d rd_loss / d z_tilde (rate term) to g_zt.  p_out / dp_out (optional): raw mass and dp/dv.
+int launch_factorized(const float* zt, const float* eb_packed, const StepCtx* ctx, int B,
+                      int npix, int C, float inv_ln2_hw, ImgSums* sums, float* g_zt, float* p_out,
+                      float* dp_out, hipStream_t s);
+
+// Gaussian conditional on y_tilde [B,h,w,C] with (mu | sigma_raw) = ms [B,hs,ws,2C] cropped to
+// [h,w] (sga.py:126-136).  Writes g_yt (rate term), g_ms [B,hs,ws,2C] (zero outside the crop).
+int launch_gaussian(const float* yt, const float* ms, const StepCtx* ctx, int B, int h, int w,
+                    int hs, int ws, int C, float inv_ln2_hw, ImgSums* sums, float* g_yt,
+                    float* g_ms, hipStream_t s);
+// unit-parity form: flat arrays, returns p and partials
+int launch_gaussian_op(const float* y, const float* mu, const float* sraw, int64_t n, float* p,
+                       float* dp_dy, float* dp_dmu, float* dp_dsraw, hipStream_t s);
+
+// distortion: sums + gradient image g = lambda*2*255^2*loss_scale/(HW3) * (xt - x) written into
+// the zero-bordered buffer gpad [B,Hp,Wp,3] at offset (2,2)  (sga.py:150-161)
+int launch_mse(const float* x, const float* xt, const StepCtx* ctx, int B, int H, int W, int Hp,
+               int Wp, ImgSums* sums, float* gpad, float* xq_out, hipStream_t s);
+
+// x [B,H,W,3] -> zero-bordered [B,Hp,Wp,3] at offset (2,2)
+int launch_pad_image(const float* x, int B, int H, int W, int Hp, int Wp, float* xp,
+                     hipStream_t s);
+
+// g = (ga + gb) * jac (chain through the sampler); optional Adam update (adam.py:20-59, f32)
+int launch_combine_grad(const float* ga, const float* gb, const float* jac, float* g, int64_t n,
+                        hipStream_t s);
+int launch_adam_latent(float* p, const float* ga, const float* gb, const float* jac, float* m,
+                       float* v, int64_t n, const StepCtx* ctx, hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1,
+                float b2, float eps, hipStream_t s);
+
+// ctx management
+int launch_set_ctx(StepCtx* ctx, int it, int its, float T, float lr_t, float lambda,
+                   float loss_scale, uint64_t seed, hipStream_t s);
+// it += 1; T = Ttab[it]; lr_t = lrtab[it]   (head of every graph replay)
+int launch_advance_ctx(StepCtx* ctx, const float* Ttab, const float* lrtab, hipStream_t s);
+
+// consume + zero the per-image sums.  scalars[3] = {rd_loss, train_mse, train_bpp}; psnr[B];
+// trace row [it][4] (if trace != null).  Any output may be null.
+int launch_finalize_step(ImgSums* sums, const StepCtx* ctx, int B, int H, int W, float* scalars,
+                         float* psnr, float* trace, hipStream_t s);
+// metrics[B][7] = {mse, psnr, msssim(=nan here), msssim_db, est_bpp, est_y_bpp, est_z_bpp}
+int launch_finalize_eval(ImgSums* sums, int B, int H, int W, float* metrics, hipStream_t s);
+
+int launch_round(const float* v, float* out, int64_t n, hipStream_t s);               // rint
+// y_hat = round(y - mu) + mu with mu = ms[..., :C] cropped (mbt2018.py:80; cfg 1)
+int launch_round_centered(const float* y, const float* ms, int B, int h, int w, int hs, int ws,
+                          int C, float* out, hipStream_t s);
+// z_hat = round(z - med[c]) + med[c]
+int launch_round_median(const float* z, const float* med, int64_t n, int C, float* out,
+                        hipStream_t s);
+int launch_fill(float* p, float val, int64_t n, hipStream_t s);
+// out = act > 0 ? g : 0  (ReLU backward; unit-parity op only, the step fuses it into conv epilogues)
+int launch_relu_mask(const float* g, const float* act, float* out, int64_t n, hipStream_t s);

@@ -1,0 +1,937 @@
+// C ABI of libsga_hip (include/sga_hip.h): handle, weight pre-packing, layer descriptors,
+// the SGA step sequence and its hipGraph replay.  No torch types, no exceptions across the ABI.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/sga_hip.h"
+#include "kernels.h"
+#include "sga_common.h"
+
+namespace {
+
+constexpr int kMaxIts = 16384;
+constexpr int BM_TILE = 128;
+
+struct PackedConv {
+  float* w = nullptr;   // device [nslab][Npad][Kc]
+  int Kc = 0;           // contiguous K per slab row (C_in of the GEMM)
+  int N = 0;            // real output channels
+  int Npad = 0, bn = 0;
+  int nslab = 0;
+};
+
+struct Buf {
+  float* p = nullptr;
+  size_t cap = 0;   // floats
+};
+
+struct Geom {
+  int B = 0, H = 0, W = 0;
+  int eh[5], ew[5];       // analysis pyramid: eh[0]=H ... eh[4]=yh   (ceil halves)
+  int yh, yw, zh1, zw1, zh, zw;
+  int hsh, hsw;           // hyper-synthesis output spatial = 4*zh, 4*zw
+  int Hp, Wp;             // zero-bordered gradient image of the synthesis output
+  int xHp, xWp;           // zero-bordered input image for the first analysis conv
+};
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+Geom make_geom(int B, int H, int W) {
+  Geom g;
+  g.B = B; g.H = H; g.W = W;
+  g.eh[0] = H; g.ew[0] = W;
+  for (int k = 1; k <= 4; ++k) { g.eh[k] = cdiv(g.eh[k - 1], 2); g.ew[k] = cdiv(g.ew[k - 1], 2); }
+  g.yh = g.eh[4]; g.yw = g.ew[4];
+  g.zh1 = cdiv(g.yh, 2); g.zw1 = cdiv(g.yw, 2);
+  g.zh = cdiv(g.zh1, 2); g.zw = cdiv(g.zw1, 2);
+  g.hsh = 4 * g.zh; g.hsw = 4 * g.zw;
+  g.Hp = 16 * g.yh + 4; g.Wp = 16 * g.yw + 4;
+  g.xHp = 2 * g.eh[1] + 4; g.xWp = 2 * g.ew[1] + 4;
+  return g;
+}
+
+}  // namespace
+
+struct sga_handle {
+  sga_config cfg;
+  int C = 0, C15 = 0, C2 = 0, haN = 0;
+  int last_hip_error = 0;
+  char last_msg[256] = {0};
+
+  // ---- packed weights (device) ----
+  PackedConv ga_f[4];            // analysis forward (ga_f[0] small-C)
+  PackedConv ga_gdn[3];
+  PackedConv gs_f[4];            // synthesis forward (gs_f[3] = combined-phase C->3)
+  PackedConv gs_b[4];            // synthesis data-gradient (gs_b[3] small-C)
+  PackedConv gs_gdn_f[3], gs_gdn_b[3];
+  PackedConv ha_f[3];
+  PackedConv hs_f[3], hs_b[3];
+  float* ga_bias[4] = {nullptr}; float* ga_beta[3] = {nullptr};
+  float* gs_bias[4] = {nullptr}; float* gs_beta[3] = {nullptr};
+  float* ha_bias[3] = {nullptr}; float* hs_bias[3] = {nullptr};
+  float* eb_packed = nullptr;
+  std::vector<void*> owned;      // every hipMalloc'd block
+
+  // ---- workspace ----
+  Buf xin, xpad, gpad, xt;
+  Buf y, z, my, vy, mz, vz, yt, dyt, zt, dzt;
+  Buf hs0, hs1, ms, g_ms, g_hs1, g_hs0, g_zt_hs, g_zt_eb;
+  Buf u[3], s[3], v[3];
+  Buf gA, gB, g_yt_dist, g_yt_rate;
+  Buf scratch;                   // scalars[4] + psnr[max_batch] + metrics[max_batch*7]
+  Buf trace, Ttab, lrtab;
+  ImgSums* sums = nullptr;
+  StepCtx* ctx = nullptr;
+  std::vector<float> hT, hLr;    // host tables (kept alive across the async upload)
+
+  Geom geom_zeroed;              // geometry for which xpad/gpad borders are known zero
+  bool borders_valid = false;
+
+  // ---- cached step graph ----
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_B = 0, graph_H = 0, graph_W = 0;
+  int use_graph = 1;
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                               \
+  do {                                                                                \
+    const int _e = (int)(expr);                                                       \
+    if (_e != 0) {                                                                    \
+      (h)->last_hip_error = _e;                                                       \
+      snprintf((h)->last_msg, sizeof((h)->last_msg), "%s:%d: %s -> %s", __FILE__,     \
+               __LINE__, #expr, hipGetErrorString((hipError_t)_e));                   \
+      return SGA_ERR_HIP;                                                             \
+    }                                                                                 \
+  } while (0)
+
+#define SGACHK(expr)                 \
+  do {                               \
+    const int _s = (expr);           \
+    if (_s != SGA_OK) return _s;     \
+  } while (0)
+
+int dev_alloc(sga_handle* h, void** p, size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    h->last_hip_error = (int)e;
+    snprintf(h->last_msg, sizeof(h->last_msg), "hipMalloc(%zu) -> %s", bytes, hipGetErrorString(e));
+    return SGA_ERR_NOMEM;
+  }
+  h->owned.push_back(*p);
+  return SGA_OK;
+}
+
+int alloc_buf(sga_handle* h, Buf& b, size_t floats) {
+  b.cap = floats;
+  void* p = nullptr;
+  SGACHK(dev_alloc(h, &p, floats * sizeof(float) + 256));   // +256 B slack for vector over-reads
+  b.p = (float*)p;
+  return SGA_OK;
+}
+
+int upload(sga_handle* h, float** dst, const float* src, size_t n) {
+  void* p = nullptr;
+  SGACHK(dev_alloc(h, &p, n * sizeof(float)));
+  HIPCHK(h, hipMemcpy(p, src, n * sizeof(float), hipMemcpyHostToDevice));
+  *dst = (float*)p;
+  return SGA_OK;
+}
+
+int upload_packed(sga_handle* h, PackedConv& pc, const std::vector<float>& host) {
+  return upload(h, &pc.w, host.data(), host.size());
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing (host).  K is HWIO [kh][kw][ci][co]  (tfc.SignalConv2D)
+// ------------------------------------------------------------------------------------------
+// GEMM with N = co, K = ci:  w[t][co][ci] = K[t][ci][co]   (forward of any conv)
+int pack_fwd(sga_handle* h, PackedConv& pc, const float* K, int taps, int ci, int co, int epi) {
+  pc.Kc = ci; pc.N = co; pc.nslab = taps;
+  pc.bn = conv_pick_bn(co, epi);
+  pc.Npad = cdiv(co, pc.bn) * pc.bn;
+  std::vector<float> w((size_t)taps * pc.Npad * ci, 0.f);
+  for (int t = 0; t < taps; ++t)
+    for (int i = 0; i < ci; ++i)
+      for (int o = 0; o < co; ++o)
+        w[((size_t)t * pc.Npad + o) * ci + i] = K[((size_t)t * ci + i) * co + o];
+  return upload_packed(h, pc, w);
+}
+
+// GEMM with N = ci, K = co:  w[t][ci][co] = K[t][ci][co]   (data-gradient of any conv)
+int pack_bwd(sga_handle* h, PackedConv& pc, const float* K, int taps, int ci, int co) {
+  pc.Kc = co; pc.N = ci; pc.nslab = taps;
+  pc.bn = conv_pick_bn(ci, EPI_BIAS);
+  pc.Npad = cdiv(ci, pc.bn) * pc.bn;
+  std::vector<float> w((size_t)taps * pc.Npad * co, 0.f);
+  for (int t = 0; t < taps; ++t)
+    for (int i = 0; i < ci; ++i)
+      memcpy(&w[((size_t)t * pc.Npad + i) * co], &K[((size_t)t * ci + i) * co], co * sizeof(float));
+  return upload_packed(h, pc, w);
+}
+
+// GDN: n_i = beta_i + sum_j gamma[j][i] x_j^2  ->  forward rows i, K = j: w[i][j] = gamma[j][i]
+//      backward acc_i = sum_k gamma[i][k] t_k   ->  rows i, K = k:          w[i][k] = gamma[i][k]
+int pack_gdn(sga_handle* h, PackedConv& pc, const float* gamma, int C, bool backward) {
+  pc.Kc = C; pc.N = C; pc.nslab = 1;
+  pc.bn = conv_pick_bn(C, EPI_BIAS);
+  pc.Npad = cdiv(C, pc.bn) * pc.bn;
+  std::vector<float> w((size_t)pc.Npad * C, 0.f);
+  for (int i = 0; i < C; ++i)
+    for (int k = 0; k < C; ++k)
+      w[(size_t)i * C + k] = backward ? gamma[(size_t)i * C + k] : gamma[(size_t)k * C + i];
+  return upload_packed(h, pc, w);
+}
+
+// C->3 transposed 5x5/2 conv as ONE GEMM over the 3x3 input neighbourhood with
+// N = 4 phases x 3 channels (padded to 32): tap (dy,dx) feeds phase (py,px) through kernel
+// element ky = py + 2 - 2dy, kx = px + 2 - 2dx when that lies inside the 5x5 support.
+int pack_shuffle3(sga_handle* h, PackedConv& pc, const float* K /*[5][5][C][3]*/, int C) {
+  pc.Kc = C; pc.N = 12; pc.nslab = 9; pc.bn = 32; pc.Npad = 32;
+  std::vector<float> w((size_t)9 * 32 * C, 0.f);
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int t = (dy + 1) * 3 + (dx + 1);
+      for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+          const int ky = py + 2 - 2 * dy, kx = px + 2 - 2 * dx;
+          if (ky < 0 || ky > 4 || kx < 0 || kx > 4) continue;
+          for (int c = 0; c < 3; ++c) {
+            const int n = (py * 2 + px) * 3 + c;
+            for (int ci = 0; ci < C; ++ci)
+              w[((size_t)t * 32 + n) * C + ci] = K[(((size_t)ky * 5 + kx) * C + ci) * 3 + c];
+          }
+        }
+    }
+  return upload_packed(h, pc, w);
+}
+
+// 5x5/2 conv over a zero-bordered 3-channel image: 3 K-steps of 32 = two kernel rows x 16
+// floats (kx*3+ch for 15, +1 slack).  fwd: N = co, element K[ky][kx][ch][co] (K is [5][5][3][C]);
+// bwd (gradient of the C->3 transposed conv): N = ci, element K[ky][kx][ci][ch] (K is [5][5][C][3]).
+int pack_smallc(sga_handle* h, PackedConv& pc, const float* K, int C, bool bwd) {
+  pc.Kc = 32; pc.N = C; pc.nslab = 3;
+  pc.bn = conv_pick_bn(C, EPI_BIAS);
+  pc.Npad = cdiv(C, pc.bn) * pc.bn;
+  std::vector<float> w((size_t)3 * pc.Npad * 32, 0.f);
+  for (int s = 0; s < 3; ++s)
+    for (int half = 0; half < 2; ++half) {
+      const int ky = 2 * s + half;
+      if (ky > 4) continue;
+      for (int kk = 0; kk < 15; ++kk) {
+        const int kx = kk / 3, ch = kk % 3;
+        for (int n = 0; n < C; ++n) {
+          const float val = bwd ? K[(((size_t)ky * 5 + kx) * C + n) * 3 + ch]
+                                : K[(((size_t)ky * 5 + kx) * 3 + ch) * C + n];
+          w[((size_t)s * pc.Npad + n) * 32 + half * 16 + kk] = val;
+        }
+      }
+    }
+  return upload_packed(h, pc, w);
+}
+
+// ------------------------------------------------------------------------------------------
+// tap tables
+// ------------------------------------------------------------------------------------------
+void taps_single(ConvArgs& a) {
+  a.nphase = 1;
+  a.ph[0] = ConvPhase{0, 0, 0, 1};
+  a.taps[0] = ConvTap{0, 0, 0};
+}
+
+// stride-2 5x5 cross-correlation, pad 2: in(2i+ky-2, 2j+kx-2)
+void taps_conv5_s2(ConvArgs& a) {
+  a.nphase = 1;
+  a.ph[0] = ConvPhase{0, 0, 0, 25};
+  for (int ky = 0; ky < 5; ++ky)
+    for (int kx = 0; kx < 5; ++kx) a.taps[ky * 5 + kx] = ConvTap{ky - 2, kx - 2, ky * 5 + kx};
+}
+
+// stride-2 transposed 5x5 conv: out(2i+py, 2j+px) = sum in(i+dy, j+dx) K[ky][kx],
+// dy = (py + 2 - ky)/2 over ky = py (mod 2).  Heaviest phase first.
+void taps_deconv5_s2(ConvArgs& a) {
+  a.nphase = 4;
+  int t = 0;
+  for (int p = 0; p < 4; ++p) {
+    const int py = p >> 1, px = p & 1;
+    a.ph[p].py = py; a.ph[p].px = px; a.ph[p].tap_begin = t;
+    for (int ky = py; ky < 5; ky += 2)
+      for (int kx = px; kx < 5; kx += 2) a.taps[t++] = ConvTap{(py + 2 - ky) / 2, (px + 2 - kx) / 2, ky * 5 + kx};
+    a.ph[p].ntaps = t - a.ph[p].tap_begin;
+  }
+}
+
+// 3x3 stride 1: corr -> in(i+ky-1); true convolution (corr=False) -> in(i+1-ky)
+void taps_conv3(ConvArgs& a, bool true_conv) {
+  a.nphase = 1;
+  a.ph[0] = ConvPhase{0, 0, 0, 9};
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx)
+      a.taps[ky * 3 + kx] = true_conv ? ConvTap{1 - ky, 1 - kx, ky * 3 + kx} : ConvTap{ky - 1, kx - 1, ky * 3 + kx};
+}
+
+void taps_shuffle3(ConvArgs& a) {
+  a.nphase = 1;
+  a.ph[0] = ConvPhase{0, 0, 0, 9};
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int t = (dy + 1) * 3 + (dx + 1);
+      a.taps[t] = ConvTap{dy, dx, t};
+    }
+}
+
+void taps_smallc(ConvArgs& a) {
+  a.nphase = 1;
+  a.ph[0] = ConvPhase{0, 0, 0, 3};
+  for (int s = 0; s < 3; ++s) a.taps[s] = ConvTap{2 * s, 0, s};
+}
+
+ConvArgs base_args(const PackedConv& pc, int B, int Hg, int Wg) {
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.w = pc.w;
+  a.B = B; a.Hg = Hg; a.Wg = Wg;
+  a.Cin = pc.Kc; a.Cout = pc.N; a.Npad = pc.Npad;
+  a.ntiles_n = pc.Npad / pc.bn;
+  a.tiles_per_phase = cdiv(B * Hg * Wg, BM_TILE);
+  a.in_cs = pc.Kc; a.out_cs = pc.N;
+  a.s_in = 1; a.s_out = 1;
+  a.pro = PRO_NONE; a.epi = EPI_BIAS;
+  return a;
+}
+
+// ---- layer launchers (all: in/out NHWC device) ---------------------------------------------
+// transposed 5x5/2: [B,Hi,Wi,Cin] -> [B,2Hi,2Wi,Cout]
+int deconv_fwd(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int B,
+               int Hi, int Wi, float* out, int epi, hipStream_t st) {
+  ConvArgs a = base_args(pc, B, Hi, Wi);
+  a.in = in; a.out = out; a.bias = bias;
+  a.Hin = Hi; a.Win = Wi; a.Hout = 2 * Hi; a.Wout = 2 * Wi;
+  a.s_in = 1; a.s_out = 2; a.epi = epi;
+  taps_deconv5_s2(a);
+  HIPCHK(h, launch_conv(a, st));
+  return SGA_OK;
+}
+
+// stride-2 5x5 conv over `in` [B,Hi,Wi,K] -> [B,Ho,Wo,N]; used for analysis forward and for the
+// data-gradient of deconv_fwd (then in = g_out, Ho = Hi/2).  aux0: ReLU-mask activation (or null)
+int conv5s2(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int B, int Hi,
+            int Wi, int Ho, int Wo, float* out, int epi, const float* aux0, hipStream_t st) {
+  ConvArgs a = base_args(pc, B, Ho, Wo);
+  a.in = in; a.out = out; a.bias = bias; a.aux0 = aux0;
+  a.Hin = Hi; a.Win = Wi; a.Hout = Ho; a.Wout = Wo;
+  a.s_in = 2; a.s_out = 1; a.epi = epi;
+  taps_conv5_s2(a);
+  HIPCHK(h, launch_conv(a, st));
+  return SGA_OK;
+}
+
+int conv3(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int in_cs, int B,
+          int Hi, int Wi, float* out, bool true_conv, int epi, const float* aux0, hipStream_t st) {
+  ConvArgs a = base_args(pc, B, Hi, Wi);
+  a.in = in; a.out = out; a.bias = bias; a.aux0 = aux0; a.in_cs = in_cs;
+  a.Hin = Hi; a.Win = Wi; a.Hout = Hi; a.Wout = Wi;
+  a.epi = epi;
+  taps_conv3(a, true_conv);
+  HIPCHK(h, launch_conv(a, st));
+  return SGA_OK;
+}
+
+// GDN / IGDN forward on u [B,Hh,Ww,C]: out = u * sqrt(n) (inverse) or u / sqrt(n); s_out = sqrt(n)
+int gdn_fwd(sga_handle* h, const PackedConv& pc, const float* beta, const float* u, int B, int Hh,
+            int Ww, float* s_out, float* out, bool inverse, hipStream_t st) {
+  ConvArgs a = base_args(pc, B, Hh, Ww);
+  a.in = u; a.out = out; a.bias = beta; a.aux0 = u; a.aux_out = s_out;
+  a.Hin = Hh; a.Win = Ww; a.Hout = Hh; a.Wout = Ww;
+  a.pro = PRO_SQUARE; a.epi = inverse ? EPI_IGDN : EPI_GDN;
+  taps_single(a);
+  HIPCHK(h, launch_conv(a, st));
+  return SGA_OK;
+}
+
+// IGDN backward: g_u = g_v * s + u * (gamma . (g_v * u / s))
+int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float* u, const float* s,
+             int B, int Hh, int Ww, float* g_u, hipStream_t st) {
+  ConvArgs a = base_args(pc, B, Hh, Ww);
+  a.in = g_v; a.aux1 = s; a.aux2 = u; a.out = g_u;
+  a.Hin = Hh; a.Win = Ww; a.Hout = Hh; a.Wout = Ww;
+  a.pro = PRO_IGDN_BWD; a.epi = EPI_IGDN_BWD;
+  taps_single(a);
+  HIPCHK(h, launch_conv(a, st));
+  return SGA_OK;
+}
+
+// C->3 transposed conv (combined phases): [B,Hi,Wi,C] -> out [B,Ho,Wo,3] cropped to (Ho,Wo)
+int deconv_to3(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int B,
+               int Hi, int Wi, int Ho, int Wo, float* out, hipStream_t st) {
+  ConvArgs a = base_args(pc, B, Hi, Wi);
+  a.in = in; a.out = out; a.bias = bias;
+  a.Hin = Hi; a.Win = Wi; a.Hout = Ho; a.Wout = Wo;
+  a.Cout = 12; a.out_cs = 3; a.epi = EPI_SHUFFLE3;
+  taps_shuffle3(a);
+  HIPCHK(h, launch_conv(a, st));
+  return SGA_OK;
+}
+
+// 5x5/2 conv over the zero-bordered 3-channel image `pad` [B,Hp,Wp,3] -> [B,Ho,Wo,C]
+int conv_smallc(sga_handle* h, const PackedConv& pc, const float* bias, const float* pad, int B,
+                int Hp, int Wp, int Ho, int Wo, float* out, hipStream_t st) {
+  ConvArgs a = base_args(pc, B, Ho, Wo);
+  a.in = pad; a.out = out; a.bias = bias;
+  a.Hin = Hp; a.Win = Wp; a.Hout = Ho; a.Wout = Wo;
+  a.s_in = 2; a.smallc = 1; a.epi = EPI_BIAS;
+  taps_smallc(a);
+  HIPCHK(h, launch_conv(a, st));
+  return SGA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+int check_shape(const sga_handle* h, int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return SGA_ERR_BAD_ARG;
+  if (B > h->cfg.max_batch || H > h->cfg.max_height || W > h->cfg.max_width) return SGA_ERR_BAD_SHAPE;
+  return SGA_OK;
+}
+
+int ensure_borders(sga_handle* h, const Geom& g, hipStream_t st) {
+  if (h->borders_valid && h->geom_zeroed.B == g.B && h->geom_zeroed.H == g.H &&
+      h->geom_zeroed.W == g.W)
+    return SGA_OK;
+  HIPCHK(h, hipMemsetAsync(h->xpad.p, 0, h->xpad.cap * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->gpad.p, 0, h->gpad.cap * sizeof(float), st));
+  h->geom_zeroed = g;
+  h->borders_valid = true;
+  return SGA_OK;
+}
+
+inline float inv_ln2_hw(const Geom& g) { return (float)(1.0 / (0.6931471805599453 * g.H * (double)g.W)); }
+
+// sga.py:77-78: y = g_a(x), z = h_a(y)
+int encode_impl(sga_handle* h, const Geom& g, const float* x, float* y, float* z, hipStream_t st) {
+  const int B = g.B, C = h->C;
+  HIPCHK(h, launch_pad_image(x, B, g.H, g.W, g.xHp, g.xWp, h->xpad.p, st));
+  // temporaries borrowed from the synthesis workspace (large enough: 8*yh >= eh[1])
+  float* ubuf = h->u[2].p; float* vbuf = h->v[2].p; float* v2buf = h->s[2].p;
+  SGACHK(conv_smallc(h, h->ga_f[0], h->ga_bias[0], h->xpad.p, B, g.xHp, g.xWp, g.eh[1], g.ew[1], ubuf, st));
+  SGACHK(gdn_fwd(h, h->ga_gdn[0], h->ga_beta[0], ubuf, B, g.eh[1], g.ew[1], nullptr, vbuf, false, st));
+  SGACHK(conv5s2(h, h->ga_f[1], h->ga_bias[1], vbuf, B, g.eh[1], g.ew[1], g.eh[2], g.ew[2], ubuf, EPI_BIAS, nullptr, st));
+  SGACHK(gdn_fwd(h, h->ga_gdn[1], h->ga_beta[1], ubuf, B, g.eh[2], g.ew[2], nullptr, v2buf, false, st));
+  SGACHK(conv5s2(h, h->ga_f[2], h->ga_bias[2], v2buf, B, g.eh[2], g.ew[2], g.eh[3], g.ew[3], ubuf, EPI_BIAS, nullptr, st));
+  SGACHK(gdn_fwd(h, h->ga_gdn[2], h->ga_beta[2], ubuf, B, g.eh[3], g.ew[3], nullptr, vbuf, false, st));
+  SGACHK(conv5s2(h, h->ga_f[3], h->ga_bias[3], vbuf, B, g.eh[3], g.ew[3], g.yh, g.yw, y, EPI_BIAS, nullptr, st));
+  // h_a (nn_models.py:85-96): conv3x3+relu, conv5x5/2+relu, conv5x5/2 (no bias)
+  float* t0 = h->hs1.p; float* t1 = h->hs0.p;
+  SGACHK(conv3(h, h->ha_f[0], h->ha_bias[0], y, C, B, g.yh, g.yw, t0, false, EPI_BIAS_RELU, nullptr, st));
+  SGACHK(conv5s2(h, h->ha_f[1], h->ha_bias[1], t0, B, g.yh, g.yw, g.zh1, g.zw1, t1, EPI_BIAS_RELU, nullptr, st));
+  SGACHK(conv5s2(h, h->ha_f[2], nullptr, t1, B, g.zh1, g.zw1, g.zh, g.zw, z, EPI_BIAS, nullptr, st));
+  return SGA_OK;
+}
+
+// forward of the rate-distortion graph given (relaxed or rounded) latents in h->yt / h->zt
+// (sga.py:100-108, 122-136, 143-150).  with_grad: also every data-gradient (sga.py:164).
+int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_grad,
+                        hipStream_t st) {
+  const int B = g.B, C = h->C;
+  const float il = inv_ln2_hw(g);
+  // ---- hyper branch: p(z_tilde), (mu, sigma) = h_s(z_tilde) -----------------------------
+  HIPCHK(h, launch_factorized(h->zt.p, h->eb_packed, h->ctx, B, g.zh * g.zw, C, il, h->sums,
+                              with_grad ? h->g_zt_eb.p : nullptr, nullptr, nullptr, st));
+  SGACHK(deconv_fwd(h, h->hs_f[0], h->hs_bias[0], h->zt.p, B, g.zh, g.zw, h->hs0.p, EPI_BIAS_RELU, st));
+  SGACHK(deconv_fwd(h, h->hs_f[1], h->hs_bias[1], h->hs0.p, B, 2 * g.zh, 2 * g.zw, h->hs1.p, EPI_BIAS_RELU, st));
+  SGACHK(conv3(h, h->hs_f[2], h->hs_bias[2], h->hs1.p, h->C15, B, g.hsh, g.hsw, h->ms.p, true, EPI_BIAS, nullptr, st));
+  // ---- p(y_tilde | z_tilde) ------------------------------------------------------------------
+  HIPCHK(h, launch_gaussian(h->yt.p, h->ms.p, h->ctx, B, g.yh, g.yw, g.hsh, g.hsw, C, il, h->sums,
+                            with_grad ? h->g_yt_rate.p : nullptr, with_grad ? h->g_ms.p : nullptr, st));
+  // ---- x_tilde = g_s(y_tilde) ------------------------------------------------------------------
+  const float* cur = h->yt.p;
+  int hh = g.yh, ww = g.yw;
+  for (int L = 0; L < 3; ++L) {
+    SGACHK(deconv_fwd(h, h->gs_f[L], h->gs_bias[L], cur, B, hh, ww, h->u[L].p, EPI_BIAS, st));
+    hh *= 2; ww *= 2;
+    SGACHK(gdn_fwd(h, h->gs_gdn_f[L], h->gs_beta[L], h->u[L].p, B, hh, ww, h->s[L].p, h->v[L].p, true, st));
+    cur = h->v[L].p;
+  }
+  SGACHK(deconv_to3(h, h->gs_f[3], h->gs_bias[3], cur, B, hh, ww, g.H, g.W, h->xt.p, st));
+  HIPCHK(h, launch_mse(x, h->xt.p, with_grad ? h->ctx : nullptr, B, g.H, g.W, g.Hp, g.Wp, h->sums,
+                       with_grad ? h->gpad.p : nullptr, nullptr, st));
+  if (!with_grad) return SGA_OK;
+  // ---- data-gradients: synthesis --------------------------------------------------------------
+  // hh,ww = 8yh,8yw: gradient w.r.t. v[2] from the bordered gradient image
+  SGACHK(conv_smallc(h, h->gs_b[3], nullptr, h->gpad.p, B, g.Hp, g.Wp, hh, ww, h->gA.p, st));
+  for (int L = 2; L >= 0; --L) {
+    SGACHK(igdn_bwd(h, h->gs_gdn_b[L], h->gA.p, h->u[L].p, h->s[L].p, B, hh, ww, h->gB.p, st));
+    float* dst = (L == 0) ? h->g_yt_dist.p : h->gA.p;
+    SGACHK(conv5s2(h, h->gs_b[L], nullptr, h->gB.p, B, hh, ww, hh / 2, ww / 2, dst, EPI_BIAS, nullptr, st));
+    hh /= 2; ww /= 2;
+  }
+  // ---- data-gradients: hyper-synthesis ----------------------------------------------------------
+  SGACHK(conv3(h, h->hs_b[2], nullptr, h->g_ms.p, 2 * C, B, g.hsh, g.hsw, h->g_hs1.p, false,
+               EPI_RELU_MASK, h->hs1.p, st));
+  SGACHK(conv5s2(h, h->hs_b[1], nullptr, h->g_hs1.p, B, g.hsh, g.hsw, 2 * g.zh, 2 * g.zw, h->g_hs0.p,
+                 EPI_RELU_MASK, h->hs0.p, st));
+  SGACHK(conv5s2(h, h->hs_b[0], nullptr, h->g_hs0.p, B, 2 * g.zh, 2 * g.zw, g.zh, g.zw, h->g_zt_hs.p,
+                 EPI_BIAS, nullptr, st));
+  return SGA_OK;
+}
+
+// one SGA evaluation: sample both latents (sga.py:86-98,111-121) then forward + backward
+int sga_step_core(sga_handle* h, const Geom& g, const float* x, const float* y, const float* z,
+                  const float* u_y, const float* u_z, hipStream_t st) {
+  const int64_t ny = (int64_t)g.B * g.yh * g.yw * h->C, nz = (int64_t)g.B * g.zh * g.zw * h->C;
+  HIPCHK(h, launch_sample(z, u_z, h->ctx, 1, h->zt.p, h->dzt.p, nz, st));
+  HIPCHK(h, launch_sample(y, u_y, h->ctx, 0, h->yt.p, h->dyt.p, ny, st));
+  return rd_forward_backward(h, g, x, true, st);
+}
+
+int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, const float* z_hat,
+              float* metrics, float* x_hat, hipStream_t st) {
+  const int64_t ny = (int64_t)g.B * g.yh * g.yw * h->C, nz = (int64_t)g.B * g.zh * g.zw * h->C;
+  HIPCHK(h, hipMemcpyAsync(h->yt.p, y_hat, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(h->zt.p, z_hat, nz * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HIPCHK(h, hipMemsetAsync(h->sums, 0, sizeof(ImgSums) * g.B, st));
+  SGACHK(rd_forward_backward(h, g, x, false, st));
+  if (metrics) HIPCHK(h, launch_finalize_eval(h->sums, g.B, g.H, g.W, metrics, st));
+  if (x_hat)
+    HIPCHK(h, hipMemcpyAsync(x_hat, h->xt.p, (size_t)g.B * g.H * g.W * 3 * sizeof(float),
+                             hipMemcpyDeviceToDevice, st));
+  return SGA_OK;
+}
+
+void free_all(sga_handle* h) {
+  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+  for (void* p : h->owned) hipFree(p);
+  h->owned.clear();
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+int sga_abi_version(void) { return SGA_ABI_VERSION; }
+
+int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
+  if (!out || !cfg || !w) return SGA_ERR_BAD_ARG;
+  *out = nullptr;
+  if (cfg->num_filters <= 0 || cfg->num_filters % 64 != 0) return SGA_ERR_UNSUPPORTED;
+  if (cfg->max_batch <= 0 || cfg->max_height <= 0 || cfg->max_width <= 0) return SGA_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return SGA_ERR_NO_DEVICE;
+  sga_handle* h = new (std::nothrow) sga_handle();
+  if (!h) return SGA_ERR_NOMEM;
+  h->cfg = *cfg;
+  const int C = cfg->num_filters;
+  h->C = C; h->C15 = (int)(C * 1.5); h->C2 = 2 * C;
+  h->haN = cfg->bits_back ? 2 * C : C;
+  int st = SGA_OK;
+  auto fail = [&](int code) { free_all(h); delete h; return code; };
+#define TRY(expr) do { st = (expr); if (st != SGA_OK) return fail(st); } while (0)
+
+  for (int i = 0; i < 4; ++i) {
+    if (!w->ga_kernel[i] || !w->ga_bias[i] || !w->gs_kernel[i] || !w->gs_bias[i]) return fail(SGA_ERR_BAD_ARG);
+  }
+  // ---- analysis ----
+  TRY(pack_smallc(h, h->ga_f[0], w->ga_kernel[0], C, false));
+  for (int i = 1; i < 4; ++i) TRY(pack_fwd(h, h->ga_f[i], w->ga_kernel[i], 25, C, C, EPI_BIAS));
+  for (int i = 0; i < 4; ++i) TRY(upload(h, &h->ga_bias[i], w->ga_bias[i], C));
+  for (int i = 0; i < 3; ++i) {
+    TRY(pack_gdn(h, h->ga_gdn[i], w->ga_gamma[i], C, false));
+    TRY(upload(h, &h->ga_beta[i], w->ga_beta[i], C));
+  }
+  // ---- synthesis ----
+  for (int i = 0; i < 3; ++i) {
+    TRY(pack_fwd(h, h->gs_f[i], w->gs_kernel[i], 25, C, C, EPI_BIAS));
+    TRY(pack_bwd(h, h->gs_b[i], w->gs_kernel[i], 25, C, C));
+    TRY(pack_gdn(h, h->gs_gdn_f[i], w->gs_gamma[i], C, false));
+    TRY(pack_gdn(h, h->gs_gdn_b[i], w->gs_gamma[i], C, true));
+    TRY(upload(h, &h->gs_beta[i], w->gs_beta[i], C));
+    TRY(upload(h, &h->gs_bias[i], w->gs_bias[i], C));
+  }
+  TRY(pack_shuffle3(h, h->gs_f[3], w->gs_kernel[3], C));
+  TRY(pack_smallc(h, h->gs_b[3], w->gs_kernel[3], C, true));
+  TRY(upload(h, &h->gs_bias[3], w->gs_bias[3], 3));
+  // ---- hyper-analysis ----
+  TRY(pack_fwd(h, h->ha_f[0], w->ha_kernel[0], 9, C, C, EPI_BIAS));
+  TRY(pack_fwd(h, h->ha_f[1], w->ha_kernel[1], 25, C, C, EPI_BIAS));
+  TRY(pack_fwd(h, h->ha_f[2], w->ha_kernel[2], 25, C, h->haN, EPI_BIAS));
+  TRY(upload(h, &h->ha_bias[0], w->ha_bias[0], C));
+  TRY(upload(h, &h->ha_bias[1], w->ha_bias[1], C));
+  // ---- hyper-synthesis ----
+  TRY(pack_fwd(h, h->hs_f[0], w->hs_kernel[0], 25, C, C, EPI_BIAS));
+  TRY(pack_fwd(h, h->hs_f[1], w->hs_kernel[1], 25, C, h->C15, EPI_BIAS));
+  TRY(pack_fwd(h, h->hs_f[2], w->hs_kernel[2], 9, h->C15, 2 * C, EPI_BIAS));
+  TRY(pack_bwd(h, h->hs_b[0], w->hs_kernel[0], 25, C, C));
+  TRY(pack_bwd(h, h->hs_b[1], w->hs_kernel[1], 25, C, h->C15));
+  TRY(pack_bwd(h, h->hs_b[2], w->hs_kernel[2], 9, h->C15, 2 * C));
+  TRY(upload(h, &h->hs_bias[0], w->hs_bias[0], C));
+  TRY(upload(h, &h->hs_bias[1], w->hs_bias[1], h->C15));
+  TRY(upload(h, &h->hs_bias[2], w->hs_bias[2], 2 * C));
+  // ---- factorized prior, packed per channel (elementwise.hip: eb_logit) ----
+  {
+    std::vector<float> P((size_t)C * EB_STRIDE, 0.f);
+    for (int c = 0; c < C; ++c) {
+      float* p = &P[(size_t)c * EB_STRIDE];
+      for (int r = 0; r < 3; ++r) {
+        p[r] = w->eb_matrix[0][c * 3 + r];
+        p[3 + r] = w->eb_bias[0][c * 3 + r];
+        p[6 + r] = w->eb_factor[0][c * 3 + r];
+      }
+      for (int layer = 0; layer < 2; ++layer) {
+        float* q = p + 9 + layer * 15;
+        for (int e = 0; e < 9; ++e) q[e] = w->eb_matrix[1 + layer][c * 9 + e];
+        for (int r = 0; r < 3; ++r) {
+          q[9 + r] = w->eb_bias[1 + layer][c * 3 + r];
+          q[12 + r] = w->eb_factor[1 + layer][c * 3 + r];
+        }
+      }
+      for (int r = 0; r < 3; ++r) p[39 + r] = w->eb_matrix[3][c * 3 + r];
+      p[42] = w->eb_bias[3][c];
+    }
+    TRY(upload(h, &h->eb_packed, P.data(), P.size()));
+  }
+
+  // ---- workspace, sized for the largest admissible batch ----
+  const Geom g = make_geom(cfg->max_batch, cfg->max_height, cfg->max_width);
+  const size_t B = g.B;
+  const size_t ny = B * g.yh * g.yw * C, nz = B * g.zh * g.zw * C;
+  TRY(alloc_buf(h, h->xin, B * g.H * g.W * 3));
+  TRY(alloc_buf(h, h->xt, B * g.H * g.W * 3));
+  TRY(alloc_buf(h, h->xpad, B * g.xHp * g.xWp * 3));
+  TRY(alloc_buf(h, h->gpad, B * g.Hp * g.Wp * 3));
+  Buf* lat_y[] = {&h->y, &h->my, &h->vy, &h->yt, &h->dyt, &h->g_yt_dist, &h->g_yt_rate};
+  for (Buf* b : lat_y) TRY(alloc_buf(h, *b, ny));
+  Buf* lat_z[] = {&h->z, &h->mz, &h->vz, &h->zt, &h->dzt, &h->g_zt_hs, &h->g_zt_eb};
+  for (Buf* b : lat_z) TRY(alloc_buf(h, *b, nz));
+  const size_t n_hs0 = B * (2 * g.zh) * (2 * g.zw) * C;
+  const size_t n_hs1 = B * g.hsh * g.hsw * h->C15;
+  const size_t n_ms = B * g.hsh * g.hsw * 2 * C;
+  TRY(alloc_buf(h, h->hs0, n_hs0)); TRY(alloc_buf(h, h->g_hs0, n_hs0));
+  TRY(alloc_buf(h, h->hs1, n_hs1)); TRY(alloc_buf(h, h->g_hs1, n_hs1));
+  TRY(alloc_buf(h, h->ms, n_ms)); TRY(alloc_buf(h, h->g_ms, n_ms));
+  for (int L = 0; L < 3; ++L) {
+    const size_t n = B * (size_t)(g.yh << (L + 1)) * (g.yw << (L + 1)) * C;
+    TRY(alloc_buf(h, h->u[L], n)); TRY(alloc_buf(h, h->s[L], n)); TRY(alloc_buf(h, h->v[L], n));
+  }
+  TRY(alloc_buf(h, h->gA, h->u[2].cap)); TRY(alloc_buf(h, h->gB, h->u[2].cap));
+  TRY(alloc_buf(h, h->scratch, 8 + B * 8));
+  TRY(alloc_buf(h, h->trace, (size_t)kMaxIts * 4));
+  TRY(alloc_buf(h, h->Ttab, kMaxIts)); TRY(alloc_buf(h, h->lrtab, kMaxIts));
+  {
+    void* p = nullptr;
+    TRY(dev_alloc(h, &p, sizeof(ImgSums) * B));
+    h->sums = (ImgSums*)p;
+    if (hipMemset(p, 0, sizeof(ImgSums) * B) != hipSuccess) return fail(SGA_ERR_HIP);
+    TRY(dev_alloc(h, &p, sizeof(StepCtx)));
+    h->ctx = (StepCtx*)p;
+    if (hipMemset(p, 0, sizeof(StepCtx)) != hipSuccess) return fail(SGA_ERR_HIP);
+  }
+  if (hipDeviceSynchronize() != hipSuccess) return fail(SGA_ERR_HIP);
+  const char* env = getenv("SGA_NO_GRAPH");
+  h->use_graph = !(env && env[0] == '1');
+#undef TRY
+  *out = h;
+  return SGA_OK;
+}
+
+int sga_destroy(sga_handle* h) {
+  if (!h) return SGA_ERR_BAD_ARG;
+  hipDeviceSynchronize();
+  free_all(h);
+  delete h;
+  return SGA_OK;
+}
+
+int sga_last_error(const sga_handle* h, char* msg, int msg_len) {
+  if (!h) return SGA_ERR_BAD_ARG;
+  if (msg && msg_len > 0) {
+    strncpy(msg, h->last_msg, (size_t)msg_len - 1);
+    msg[msg_len - 1] = 0;
+  }
+  return h->last_hip_error;
+}
+
+int sga_latent_shape(const sga_handle* h, int H, int W, int* yh, int* yw, int* zh, int* zw) {
+  if (!h || H <= 0 || W <= 0) return SGA_ERR_BAD_ARG;
+  const Geom g = make_geom(1, H, W);
+  if (yh) *yh = g.yh;
+  if (yw) *yw = g.yw;
+  if (zh) *zh = g.zh;
+  if (zw) *zw = g.zw;
+  return SGA_OK;
+}
+
+int sga_encode(sga_handle* h, const float* x, int B, int H, int W, float* y, float* z,
+               void* stream) {
+  if (!h || !x || !y || !z) return SGA_ERR_BAD_ARG;
+  SGACHK(check_shape(h, B, H, W));
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(B, H, W);
+  SGACHK(ensure_borders(h, g, st));
+  return encode_impl(h, g, x, y, z, st);
+}
+
+int sga_step_grads(sga_handle* h, const float* x, int B, int H, int W, const float* y,
+                   const float* z, float T, float lambda, float loss_scale, uint64_t seed,
+                   uint32_t it, const float* u_y, const float* u_z, float* gy, float* gz,
+                   float* scalars, float* psnr, void* stream) {
+  if (!h || !x || !y || !z || !(T > 0.f)) return SGA_ERR_BAD_ARG;
+  SGACHK(check_shape(h, B, H, W));
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(B, H, W);
+  SGACHK(ensure_borders(h, g, st));
+  HIPCHK(h, launch_set_ctx(h->ctx, (int)it, 0, T, 0.f, lambda, loss_scale, seed, st));
+  HIPCHK(h, hipMemsetAsync(h->sums, 0, sizeof(ImgSums) * B, st));
+  SGACHK(sga_step_core(h, g, x, y, z, u_y, u_z, st));
+  const int64_t ny = (int64_t)B * g.yh * g.yw * h->C, nz = (int64_t)B * g.zh * g.zw * h->C;
+  if (gy) HIPCHK(h, launch_combine_grad(h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, gy, ny, st));
+  if (gz) HIPCHK(h, launch_combine_grad(h->g_zt_hs.p, h->g_zt_eb.p, h->dzt.p, gz, nz, st));
+  HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, scalars, psnr, nullptr, st));
+  return SGA_OK;
+}
+
+int sga_adam(sga_handle* h, float* p, const float* g, float* m, float* v, int64_t n, int t,
+             float lr, float beta1, float beta2, float eps, void* stream) {
+  if (!h || !p || !g || !m || !v || n <= 0 || t <= 0) return SGA_ERR_BAD_ARG;
+  // adam.py:40-42 in double, cast to float32 at the multiply
+  const double lr_t = (double)lr * (std::sqrt(1.0 - std::pow((double)beta2, t)) /
+                                    (1.0 - std::pow((double)beta1, t)));
+  HIPCHK(h, launch_adam(p, g, m, v, n, (float)lr_t, beta1, beta2, eps, (hipStream_t)stream));
+  return SGA_OK;
+}
+
+int sga_eval(sga_handle* h, const float* x, int B, int H, int W, const float* y_hat,
+             const float* z_hat, float* metrics, float* x_hat, void* stream) {
+  if (!h || !x || !y_hat || !z_hat) return SGA_ERR_BAD_ARG;
+  SGACHK(check_shape(h, B, H, W));
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(B, H, W);
+  SGACHK(ensure_borders(h, g, st));
+  return eval_impl(h, g, x, y_hat, z_hat, metrics, x_hat, st);
+}
+
+int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, float loss_scale,
+            int its, float lr, float annealing_rate, int t0, float T_ub, uint64_t seed,
+            const float* y0, const float* z0, float* y_hat, float* z_hat, float* metrics,
+            float* trace, void* stream) {
+  if (!h || !x || its < 0 || its > kMaxIts || (y0 == nullptr) != (z0 == nullptr)) return SGA_ERR_BAD_ARG;
+  SGACHK(check_shape(h, B, H, W));
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(B, H, W);
+  const int C = h->C;
+  const int64_t ny = (int64_t)B * g.yh * g.yw * C, nz = (int64_t)B * g.zh * g.zw * C;
+  SGACHK(ensure_borders(h, g, st));
+  // x is kept in handle-owned memory so the captured graph does not depend on caller pointers
+  HIPCHK(h, hipMemcpyAsync(h->xin.p, x, (size_t)B * H * W * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (y0) {
+    HIPCHK(h, hipMemcpyAsync(h->y.p, y0, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->z.p, z0, nz * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else {
+    SGACHK(encode_impl(h, g, h->xin.p, h->y.p, h->z.p, st));
+  }
+  // fresh optimiser per batch (sga.py:208)
+  HIPCHK(h, hipMemsetAsync(h->my.p, 0, ny * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->vy.p, 0, ny * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->mz.p, 0, nz * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->vz.p, 0, nz * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->sums, 0, sizeof(ImgSums) * B, st));
+
+  if (its > 0) {
+    // host tables: utils.py:166-180 ('exp0') and adam.py:40-42, evaluated in double
+    h->hT.resize(its); h->hLr.resize(its);
+    for (int it = 0; it < its; ++it) {
+      double tau = (double)T_ub * std::exp(-(double)annealing_rate * (double)(it - t0));
+      tau = std::fmin(std::fmax(tau, 1e-8), (double)T_ub);
+      h->hT[it] = (float)tau;
+      const int t = it + 1;
+      h->hLr[it] = (float)((double)lr * (std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t))));
+    }
+    // previous run's tables may still be in use on this stream only; same-stream order suffices
+    HIPCHK(h, hipMemcpyAsync(h->Ttab.p, h->hT.data(), its * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->lrtab.p, h->hLr.data(), its * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));   // host vectors may now be reused
+    HIPCHK(h, launch_set_ctx(h->ctx, -1, its, 0.f, 0.f, lambda, loss_scale, seed, st));
+
+    auto enqueue_step = [&](hipStream_t s) -> int {
+      HIPCHK(h, launch_advance_ctx(h->ctx, h->Ttab.p, h->lrtab.p, s));
+      SGACHK(sga_step_core(h, g, h->xin.p, h->y.p, h->z.p, nullptr, nullptr, s));
+      HIPCHK(h, launch_adam_latent(h->y.p, h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, h->my.p, h->vy.p, ny, h->ctx, s));
+      HIPCHK(h, launch_adam_latent(h->z.p, h->g_zt_hs.p, h->g_zt_eb.p, h->dzt.p, h->mz.p, h->vz.p, nz, h->ctx, s));
+      HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, nullptr, nullptr, h->trace.p, s));
+      return SGA_OK;
+    };
+
+    bool graphed = false;
+    if (h->use_graph) {
+      if (!h->graph_exec || h->graph_B != B || h->graph_H != H || h->graph_W != W) {
+        if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          const int rc = enqueue_step(st);
+          const hipError_t ec = hipStreamEndCapture(st, &graph);
+          if (rc == SGA_OK && ec == hipSuccess && graph &&
+              hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            h->graph_B = B; h->graph_H = H; h->graph_W = W;
+          } else {
+            h->graph_exec = nullptr;
+          }
+          if (graph) hipGraphDestroy(graph);
+        }
+        (void)hipGetLastError();
+      }
+      graphed = h->graph_exec != nullptr;
+    }
+    for (int it = 0; it < its; ++it) {
+      if (graphed) HIPCHK(h, hipGraphLaunch(h->graph_exec, st));
+      else SGACHK(enqueue_step(st));
+    }
+    if (trace)
+      HIPCHK(h, hipMemcpyAsync(trace, h->trace.p, (size_t)its * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  // sga.py:240-247: round (half-to-even) and evaluate with the latents fed directly
+  float* yh_dst = y_hat ? y_hat : h->g_yt_dist.p;
+  float* zh_dst = z_hat ? z_hat : h->g_zt_hs.p;
+  HIPCHK(h, launch_round(h->y.p, yh_dst, ny, st));
+  HIPCHK(h, launch_round(h->z.p, zh_dst, nz, st));
+  if (metrics) SGACHK(eval_impl(h, g, h->xin.p, yh_dst, zh_dst, metrics, nullptr, st));
+  return SGA_OK;
+}
+
+int sga_base_compress(sga_handle* h, const float* x, int B, int H, int W, const float* medians,
+                      float* y_hat, float* z_hat, float* metrics, void* stream) {
+  if (!h || !x || !y_hat || !z_hat) return SGA_ERR_BAD_ARG;
+  SGACHK(check_shape(h, B, H, W));
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(B, H, W);
+  const int C = h->C;
+  const int64_t nz = (int64_t)B * g.zh * g.zw * C;
+  SGACHK(ensure_borders(h, g, st));
+  SGACHK(encode_impl(h, g, x, h->y.p, h->z.p, st));
+  HIPCHK(h, launch_round_median(h->z.p, medians, nz, C, z_hat, st));           // mbt2018.py:69
+  // mu = h_s(z_hat)[..., :C] (mbt2018.py:70-76), y_hat = round(y - mu) + mu (mbt2018.py:80)
+  SGACHK(deconv_fwd(h, h->hs_f[0], h->hs_bias[0], z_hat, B, g.zh, g.zw, h->hs0.p, EPI_BIAS_RELU, st));
+  SGACHK(deconv_fwd(h, h->hs_f[1], h->hs_bias[1], h->hs0.p, B, 2 * g.zh, 2 * g.zw, h->hs1.p, EPI_BIAS_RELU, st));
+  SGACHK(conv3(h, h->hs_f[2], h->hs_bias[2], h->hs1.p, h->C15, B, g.hsh, g.hsw, h->ms.p, true, EPI_BIAS, nullptr, st));
+  HIPCHK(h, launch_round_centered(h->y.p, h->ms.p, B, g.yh, g.yw, g.hsh, g.hsw, C, y_hat, st));
+  if (metrics) SGACHK(eval_impl(h, g, x, y_hat, z_hat, metrics, nullptr, st));
+  return SGA_OK;
+}
+
+// ---- per-layer operator surface ---------------------------------------------------------------
+int sga_op_layer_fwd(sga_handle* h, int layer, const float* in, int B, int Hin, int Win,
+                     float* out, void* stream) {
+  if (!h || !in || !out || B <= 0 || Hin <= 0 || Win <= 0) return SGA_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int C = h->C;
+  const int Ho2 = cdiv(Hin, 2), Wo2 = cdiv(Win, 2);
+  const size_t npx_in = (size_t)B * Hin * Win;
+  switch (layer) {
+    case SGA_GA0: {
+      const int Hp = 2 * Ho2 + 4, Wp = 2 * Wo2 + 4;
+      if ((size_t)B * Hp * Wp * 3 > h->xpad.cap || (size_t)B * Ho2 * Wo2 * C > h->u[2].cap) return SGA_ERR_BAD_SHAPE;
+      HIPCHK(h, hipMemsetAsync(h->xpad.p, 0, h->xpad.cap * sizeof(float), st));
+      h->borders_valid = false;
+      HIPCHK(h, launch_pad_image(in, B, Hin, Win, Hp, Wp, h->xpad.p, st));
+      SGACHK(conv_smallc(h, h->ga_f[0], h->ga_bias[0], h->xpad.p, B, Hp, Wp, Ho2, Wo2, h->u[2].p, st));
+      return gdn_fwd(h, h->ga_gdn[0], h->ga_beta[0], h->u[2].p, B, Ho2, Wo2, nullptr, out, false, st);
+    }
+    case SGA_GA1: case SGA_GA2: {
+      const int i = layer - SGA_GA0;
+      if ((size_t)B * Ho2 * Wo2 * C > h->u[2].cap) return SGA_ERR_BAD_SHAPE;
+      SGACHK(conv5s2(h, h->ga_f[i], h->ga_bias[i], in, B, Hin, Win, Ho2, Wo2, h->u[2].p, EPI_BIAS, nullptr, st));
+      return gdn_fwd(h, h->ga_gdn[i], h->ga_beta[i], h->u[2].p, B, Ho2, Wo2, nullptr, out, false, st);
+    }
+    case SGA_GA3:
+      return conv5s2(h, h->ga_f[3], h->ga_bias[3], in, B, Hin, Win, Ho2, Wo2, out, EPI_BIAS, nullptr, st);
+    case SGA_GS0: case SGA_GS1: case SGA_GS2: {
+      const int i = layer - SGA_GS0;
+      if (npx_in * 4 * C > h->u[2].cap) return SGA_ERR_BAD_SHAPE;
+      SGACHK(deconv_fwd(h, h->gs_f[i], h->gs_bias[i], in, B, Hin, Win, h->u[2].p, EPI_BIAS, st));
+      return gdn_fwd(h, h->gs_gdn_f[i], h->gs_beta[i], h->u[2].p, B, 2 * Hin, 2 * Win, h->s[2].p, out, true, st);
+    }
+    case SGA_GS3:
+      return deconv_to3(h, h->gs_f[3], h->gs_bias[3], in, B, Hin, Win, 2 * Hin, 2 * Win, out, st);
+    case SGA_HA0:
+      return conv3(h, h->ha_f[0], h->ha_bias[0], in, C, B, Hin, Win, out, false, EPI_BIAS_RELU, nullptr, st);
+    case SGA_HA1:
+      return conv5s2(h, h->ha_f[1], h->ha_bias[1], in, B, Hin, Win, Ho2, Wo2, out, EPI_BIAS_RELU, nullptr, st);
+    case SGA_HA2:
+      return conv5s2(h, h->ha_f[2], nullptr, in, B, Hin, Win, Ho2, Wo2, out, EPI_BIAS, nullptr, st);
+    case SGA_HS0:
+      return deconv_fwd(h, h->hs_f[0], h->hs_bias[0], in, B, Hin, Win, out, EPI_BIAS_RELU, st);
+    case SGA_HS1:
+      return deconv_fwd(h, h->hs_f[1], h->hs_bias[1], in, B, Hin, Win, out, EPI_BIAS_RELU, st);
+    case SGA_HS2:
+      return conv3(h, h->hs_f[2], h->hs_bias[2], in, h->C15, B, Hin, Win, out, true, EPI_BIAS, nullptr, st);
+  }
+  return SGA_ERR_UNSUPPORTED;
+}
+
+int sga_op_layer_bwd(sga_handle* h, int layer, const float* in, const float* g_out, int B,
+                     int Hin, int Win, float* g_in, void* stream) {
+  if (!h || !in || !g_out || !g_in || B <= 0 || Hin <= 0 || Win <= 0) return SGA_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int C = h->C;
+  const size_t npx_in = (size_t)B * Hin * Win;
+  switch (layer) {
+    case SGA_GS0: case SGA_GS1: case SGA_GS2: {
+      const int i = layer - SGA_GS0;
+      if (npx_in * 4 * C > h->u[2].cap) return SGA_ERR_BAD_SHAPE;
+      // recompute u and s = sqrt(n), then IGDN backward, then the transposed conv's data-gradient
+      SGACHK(deconv_fwd(h, h->gs_f[i], h->gs_bias[i], in, B, Hin, Win, h->u[2].p, EPI_BIAS, st));
+      SGACHK(gdn_fwd(h, h->gs_gdn_f[i], h->gs_beta[i], h->u[2].p, B, 2 * Hin, 2 * Win, h->s[2].p, h->v[2].p, true, st));
+      SGACHK(igdn_bwd(h, h->gs_gdn_b[i], g_out, h->u[2].p, h->s[2].p, B, 2 * Hin, 2 * Win, h->gB.p, st));
+      return conv5s2(h, h->gs_b[i], nullptr, h->gB.p, B, 2 * Hin, 2 * Win, Hin, Win, g_in, EPI_BIAS, nullptr, st);
+    }
+    case SGA_GS3: {
+      const int Hp = 2 * Hin + 4, Wp = 2 * Win + 4;
+      if ((size_t)B * Hp * Wp * 3 > h->gpad.cap) return SGA_ERR_BAD_SHAPE;
+      HIPCHK(h, hipMemsetAsync(h->gpad.p, 0, h->gpad.cap * sizeof(float), st));
+      h->borders_valid = false;
+      HIPCHK(h, launch_pad_image(g_out, B, 2 * Hin, 2 * Win, Hp, Wp, h->gpad.p, st));
+      return conv_smallc(h, h->gs_b[3], nullptr, h->gpad.p, B, Hp, Wp, Hin, Win, g_in, st);
+    }
+    case SGA_HS0: case SGA_HS1: {
+      // g_out is the gradient w.r.t. the ReLU output: mask with the recomputed activation
+      const int i = layer - SGA_HS0;
+      const int Co = (i == 0) ? C : h->C15;
+      if (npx_in * 4 * Co > h->g_hs1.cap || npx_in * 4 * Co > h->hs1.cap) return SGA_ERR_BAD_SHAPE;
+      SGACHK(deconv_fwd(h, h->hs_f[i], h->hs_bias[i], in, B, Hin, Win, h->hs1.p, EPI_BIAS_RELU, st));
+      HIPCHK(h, launch_relu_mask(g_out, h->hs1.p, h->g_hs1.p, (int64_t)npx_in * 4 * Co, st));
+      return conv5s2(h, h->hs_b[i], nullptr, h->g_hs1.p, B, 2 * Hin, 2 * Win, Hin, Win, g_in, EPI_BIAS, nullptr, st);
+    }
+    case SGA_HS2:
+      return conv3(h, h->hs_b[2], nullptr, g_out, 2 * C, B, Hin, Win, g_in, false, EPI_BIAS, nullptr, st);
+  }
+  return SGA_ERR_UNSUPPORTED;
+}
+
+int sga_op_sample(sga_handle* h, const float* v, const float* u, int64_t n, float T, float* v_tilde,
+                  float* dvt_dv, void* stream) {
+  if (!h || !v || !u || !v_tilde || n <= 0 || !(T > 0.f)) return SGA_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(h, launch_set_ctx(h->ctx, 0, 0, T, 0.f, 0.f, 1.f, 0, st));
+  HIPCHK(h, launch_sample(v, u, h->ctx, 0, v_tilde, dvt_dv, n, st));
+  return SGA_OK;
+}
+
+int sga_op_factorized_likelihood(sga_handle* h, const float* v, int64_t n_pix, float* p,
+                                 float* dp_dv, void* stream) {
+  if (!h || !v || n_pix <= 0 || n_pix * h->C > 0x7fffffffLL) return SGA_ERR_BAD_ARG;
+  HIPCHK(h, launch_factorized(v, h->eb_packed, nullptr, 1, (int)n_pix, h->C, 1.f, nullptr, nullptr, p,
+                              dp_dv, (hipStream_t)stream));
+  return SGA_OK;
+}
+
+int sga_op_gaussian_likelihood(sga_handle* h, const float* y, const float* mu,
+                               const float* sigma_raw, int64_t n, float* p, float* dp_dy,
+                               float* dp_dmu, float* dp_dsraw, void* stream) {
+  if (!h || !y || !mu || !sigma_raw || n <= 0) return SGA_ERR_BAD_ARG;
+  HIPCHK(h, launch_gaussian_op(y, mu, sigma_raw, n, p, dp_dy, dp_dmu, dp_dsraw, (hipStream_t)stream));
+  return SGA_OK;
+}
+
+}  // extern "C"

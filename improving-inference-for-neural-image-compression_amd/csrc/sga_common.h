@@ -1,0 +1,84 @@
+// Shared device/host definitions of libsga_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Per-step scalars live in DEVICE memory so that one captured hipGraph of the step
+// sequence can be replayed for every SGA iteration (sga.py:210-215): a 1-thread kernel
+// advances `it` and refreshes T / lr_t from tables at the head of each replay.
+struct StepCtx {
+  int it;             // SGA iteration index (sga.py:210)
+  int its;            // total iterations of this run
+  float T;            // temperature, utils.py:166-180
+  float lr_t;         // bias-corrected Adam step size, adam.py:40-42
+  float lambda;       // sga.py:161
+  float loss_scale;   // 1/B_ref: the batch means of sga.py:147,150
+  unsigned seed_lo, seed_hi;
+};
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011).  Bit-identical restatement in oracle/philox.py.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c0;
+    const uint64_t p1 = (uint64_t)M1 * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__host__ __device__ inline float bits_to_uniform(uint32_t b) {
+  // ((b >> 8) + 0.5) * 2^-24: strictly inside (0,1), exact in f32
+  return ((float)(b >> 8) + 0.5f) * 5.9604644775390625e-08f;
+}
+
+// ---------------------------------------------------------------------------------------
+// Convolution launcher (conv_mfma.hip)
+// ---------------------------------------------------------------------------------------
+enum ConvPrologue { PRO_NONE = 0, PRO_SQUARE = 1, PRO_IGDN_BWD = 2 };
+enum ConvEpilogue {
+  EPI_BIAS = 0,       // out = acc + bias (bias may be null)
+  EPI_BIAS_RELU = 1,  // out = max(acc + bias, 0)
+  EPI_IGDN = 2,       // n = acc + beta; s = sqrt(n); aux_out = s; out = aux0(u) * s
+  EPI_GDN = 3,        // out = aux0(u) / sqrt(acc + beta)
+  EPI_IGDN_BWD = 4,   // out = in(g) * aux1(s) + aux2(u) * acc
+  EPI_RELU_MASK = 5,  // out = aux0 > 0 ? acc : 0
+  EPI_SHUFFLE3 = 6    // 12 columns = 4 sub-pixel phases x 3 channels of a C->3 deconv
+};
+
+struct ConvTap { int dy, dx, slab; };
+struct ConvPhase { int py, px, tap_begin, ntaps; };
+
+// One gather-GEMM convolution:  out[pix(m), n] = epi( sum_{tap, ci} pro(in[pix_in(m,tap), ci]) * w[slab(tap)][n][ci] )
+// over a pixel grid m = (b, i, j), i < Hg, j < Wg, per sub-pixel phase:
+//   input  pixel (s_in*i + dy, s_in*j + dx)   (zero outside [0,Hin) x [0,Win))
+//   output pixel (s_out*i + py, s_out*j + px)
+struct ConvArgs {
+  const float* in;  const float* w;  const float* bias;  float* out;
+  const float* aux0; const float* aux1; const float* aux2; float* aux_out;
+  int in_cs, in_coff;      // channel stride / offset of `in` (and aux1/aux2 in PRO_IGDN_BWD)
+  int out_cs, out_coff;    // channel stride / offset of `out` (and aux0/aux_out)
+  int B, Hg, Wg;
+  int Hin, Win, Cin;       // Cin % 32 == 0
+  int Hout, Wout, Cout, Npad;
+  int s_in, s_out;
+  int nphase, tiles_per_phase, ntiles_n;
+  int smallc;              // 1: `in` is a zero-padded 3-channel image [B,Hin,Win,3], 5x5/2 conv
+  int pro, epi;
+  ConvPhase ph[4];
+  ConvTap taps[28];
+};
+
+// returns hipError_t
+int launch_conv(const ConvArgs& a, hipStream_t stream);
+// tile sizes chosen for an output width (host-side, also used to size Npad when packing)
+int conv_pick_bn(int cout, int epi);

@@ -1,0 +1,156 @@
+/*
+ * sga_hip.h -- C ABI of the MI355X-native SGA hot path (libsga_hip.so, gfx950 only).
+ *
+ * The reference (mandt-lab/improving-inference-for-neural-image-compression) has no
+ * plugin/FFI layer: sga.py is a monolithic TF1 script and the hot path sits behind four
+ * tf.Session interactions.  Each entry point below replaces one of them:
+ *
+ *   sga_create / sga_destroy   <- tf.train.Saver().restore(sess, latest)          sga.py:180-182
+ *   sga_encode                 <- sess.run([y_init, z_init], {x})                 sga.py:207
+ *   sga_step_grads + sga_adam  <- sess.run([rd_gradients, rd_loss, train_mse,
+ *                                  train_bpp, psnr], {y,z,x,T}) + Adam.update     sga.py:212-215
+ *   sga_run                    <- the whole per-batch loop                        sga.py:207-247
+ *   sga_eval                   <- sess.run(eval_tensors, {y_tilde:..,z_tilde:..}) sga.py:219-225,244-245
+ *   sga_op_*                   <- the per-layer operators nn_models.py composes   nn_models.py:14-163
+ *                                 and the entropy-model / sampler ops             sga.py:86-136
+ *
+ * Conventions
+ *   - every `float*` / `const float*` data argument is DEVICE memory (owned by the caller,
+ *     e.g. a PyTorch-ROCm tensor), float32, NHWC, contiguous; `sga_weights` members are HOST
+ *     pointers (read once by sga_create).
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous w.r.t. the host
+ *     unless stated otherwise; the caller synchronises.
+ *   - return 0 on success, a negative sga_status on error; no C++ exception crosses the ABI.
+ *   - no allocation after sga_create (the workspace is sized from sga_config), so the step
+ *     sequence is hipGraph-capturable; sga_run captures and replays it itself.
+ *   - a handle is NOT thread-safe: one handle per (GPU, stream), one process per GPU.
+ */
+#ifndef SGA_HIP_H_
+#define SGA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGA_ABI_VERSION 1
+
+typedef enum sga_status {
+  SGA_OK = 0,
+  SGA_ERR_BAD_ARG = -1,       /* null pointer, non-positive size */
+  SGA_ERR_BAD_SHAPE = -2,     /* B/H/W exceed the handle's workspace */
+  SGA_ERR_UNSUPPORTED = -3,   /* num_filters not a multiple of 64, unknown op */
+  SGA_ERR_HIP = -4,           /* a HIP call / launch failed: see sga_last_error */
+  SGA_ERR_NO_DEVICE = -5,     /* no gfx950 device visible */
+  SGA_ERR_NOMEM = -6
+} sga_status;
+
+typedef struct sga_handle sga_handle;
+
+typedef struct sga_config {
+  int32_t num_filters;   /* C: 192 or 256 in the reference (README.md:58-60); any multiple of 64 */
+  int32_t max_batch;     /* workspace is sized for [max_batch, max_height, max_width, 3] */
+  int32_t max_height;
+  int32_t max_width;
+  int32_t bits_back;     /* 0: mbt2018 (sga.py); 1: mbt2018_bb, h_a emits 2C (bb_sga.py:69) */
+  int32_t reserved[3];
+} sga_config;
+
+/* Effective (post-reparameterisation) parameters, HOST float32.  Kernels are HWIO
+ * (kh,kw,C_in,C_out) as tfc.SignalConv2D stores them; gamma is [C_in(j)][C_out(i)];
+ * the factorized-prior tensors are softplus(matrix_k) / bias_k / tanh(factor_k) with the
+ * shapes of learned_prior.py:43-66. */
+typedef struct sga_weights {
+  const float* ga_kernel[4];  const float* ga_bias[4];   /* AnalysisTransform        nn_models.py:14-29  */
+  const float* ga_beta[3];    const float* ga_gamma[3];
+  const float* gs_kernel[4];  const float* gs_bias[4];   /* SynthesisTransform       nn_models.py:48-63  */
+  const float* gs_beta[3];    const float* gs_gamma[3];
+  const float* ha_kernel[3];  const float* ha_bias[3];   /* HyperAnalysis (bias[2]=NULL) nn_models.py:85-96 */
+  const float* hs_kernel[3];  const float* hs_bias[3];   /* MBT2018HyperSynthesis    nn_models.py:152-163 */
+  const float* eb_matrix[4];  const float* eb_bias[4];   /* factorized prior         learned_prior.py:43-66 */
+  const float* eb_factor[3];
+} sga_weights;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int sga_abi_version(void);
+int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w);
+int sga_destroy(sga_handle* h);
+/* hipError_t of the last failing HIP call on this handle (0 if none); msg may be NULL */
+int sga_last_error(const sga_handle* h, char* msg, int msg_len);
+/* latent geometry for an HxW image: y is [h,w,C], z is [hz,wz,C] (sga.py:77-78) */
+int sga_latent_shape(const sga_handle* h, int H, int W, int* yh, int* yw, int* zh, int* zw);
+
+/* ---- sga.py:207  y_init, z_init = sess.run([y_init, z_init], {x}) ---------------------- */
+int sga_encode(sga_handle* h, const float* x, int B, int H, int W,
+               float* y, float* z, void* stream);
+
+/* ---- sga.py:212-214  one evaluation of rd_gradients and the logged scalars --------------
+ * Noise: if u_y/u_z are non-NULL they hold the uniforms in (0,1), shape latent+(2,) with
+ * [...,0] the DOWN(floor) and [...,1] the UP(ceil) draw; if NULL the device Philox4x32-10
+ * stream keyed by (seed, it) is used (bit-identical to oracle/philox.py).
+ * loss_scale = 1/B_ref (the reference's batch means, sga.py:147,150).
+ * Outputs: gy,gz = d rd_loss / d y,z; scalars[3] = {rd_loss, train_mse, train_bpp};
+ * psnr[B] (sga.py:174 on the relaxed sample).  Any output pointer may be NULL. */
+int sga_step_grads(sga_handle* h, const float* x, int B, int H, int W,
+                   const float* y, const float* z, float T, float lambda, float loss_scale,
+                   uint64_t seed, uint32_t it, const float* u_y, const float* u_z,
+                   float* gy, float* gz, float* scalars, float* psnr, void* stream);
+
+/* ---- adam.py:20-59  one update of one array, t = iterations+1 (float32 arithmetic) ------ */
+int sga_adam(sga_handle* h, float* p, const float* g, float* m, float* v, int64_t n, int t,
+             float lr, float beta1, float beta2, float eps, void* stream);
+
+/* ---- sga.py:207-247  encode + `its` x (sample, fwd, bwd, Adam) + round + eval -----------
+ * y_hat/z_hat: rounded latents (np.round, half-to-even); metrics[B][7] in the order of
+ * sga.py:183 {mse, psnr, msssim, msssim_db, est_bpp, est_y_bpp, est_z_bpp};
+ * trace[its][4] = {rd_loss, train_mse, train_bpp, mean psnr} per step, or NULL.
+ * y0/z0: optional initial latents (NULL -> sga_encode(x)). */
+int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, float loss_scale,
+            int its, float lr, float annealing_rate, int t0, float T_ub, uint64_t seed,
+            const float* y0, const float* z0,
+            float* y_hat, float* z_hat, float* metrics, float* trace, void* stream);
+
+/* ---- sga.py:219-225,244-245  eval with the latents fed directly (no sampler) ------------ */
+int sga_eval(sga_handle* h, const float* x, int B, int H, int W,
+             const float* y_hat, const float* z_hat, float* metrics, float* x_hat, void* stream);
+
+/* ---- mbt2018.py:64-81,167-180 (cfg 1, estimated-rate path): one-shot encode ------------- */
+int sga_base_compress(sga_handle* h, const float* x, int B, int H, int W, const float* medians,
+                      float* y_hat, float* z_hat, float* metrics, void* stream);
+
+/* ---- per-layer operator surface (unit parity; weights are the handle's) ------------------
+ * `layer` selects the handle's layer; shapes follow nn_models.py.  in/out NHWC. */
+typedef enum sga_layer {
+  SGA_GA0 = 0, SGA_GA1, SGA_GA2, SGA_GA3,     /* conv5x5/2 (+GDN for 0..2)   nn_models.py:14-29  */
+  SGA_GS0, SGA_GS1, SGA_GS2, SGA_GS3,         /* deconv5x5^2 (+IGDN 0..2)    nn_models.py:48-63  */
+  SGA_HA0, SGA_HA1, SGA_HA2,                  /* conv3x3+relu, conv5x5/2+relu, conv5x5/2  :85-96 */
+  SGA_HS0, SGA_HS1, SGA_HS2                   /* deconv+relu, deconv+relu, conv3x3 true   :152-163 */
+} sga_layer;
+
+/* forward of one layer INCLUDING its activation; (Hin,Win) input spatial size */
+int sga_op_layer_fwd(sga_handle* h, int layer, const float* in, int B, int Hin, int Win,
+                     float* out, void* stream);
+/* data-gradient of one synthesis / hyper-synthesis layer (GS*, HS*): g_out -> g_in.
+ * `in` is the layer input of the forward pass (needed by IGDN / ReLU backward). */
+int sga_op_layer_bwd(sga_handle* h, int layer, const float* in, const float* g_out,
+                     int B, int Hin, int Win, float* g_in, void* stream);
+
+/* SGA relaxation, sga.py:86-98/111-121: v -> v_tilde and d v_tilde / d v (u as sga_step_grads) */
+int sga_op_sample(sga_handle* h, const float* v, const float* u, int64_t n, float T,
+                  float* v_tilde, float* dvt_dv, void* stream);
+/* factorized-prior mass p(v) (tfc EntropyBottleneck._likelihood, sga.py:101) and dp/dv;
+ * v is [n_pix, C] */
+int sga_op_factorized_likelihood(sga_handle* h, const float* v, int64_t n_pix,
+                                 float* p, float* dp_dv, void* stream);
+/* box-convolved Gaussian mass (sga.py:130-133, utils.py:80-102) and its partials
+ * w.r.t. y, mu and sigma_raw (sigma = exp(sigma_raw), bounded below by 0.11) */
+int sga_op_gaussian_likelihood(sga_handle* h, const float* y, const float* mu,
+                               const float* sigma_raw, int64_t n,
+                               float* p, float* dp_dy, float* dp_dmu, float* dp_dsraw,
+                               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGA_HIP_H_ */

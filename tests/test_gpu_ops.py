@@ -1,0 +1,225 @@
+"""GPU parity, operator level: every HIP kernel behind the C ABI against the CPU oracle on the
+same seeded inputs (SURVEY.md 8(c) known-answer tests 1-7).  Tolerances are for float32
+summation-order differences between the MFMA fmaf chain and oneDNN; written per test."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import sga_amd  # noqa: E402
+from oracle.sga_oracle import SGAOracle, AdamF32, lower_bound  # noqa: E402
+
+_CODECS = {}
+
+
+def get_codec(C):
+    from sga_amd.codec import SGACodec
+    if C not in _CODECS:
+        w = sga_amd.make_synthetic_weights(C, seed=0)
+        _CODECS[C] = (SGACodec(w, C, max_batch=4, max_height=96, max_width=96), SGAOracle(w),
+                      SGAOracle(w, dtype=torch.float64), w)
+    return _CODECS[C]
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def report(gpu_out_dir, name, **kw):
+    with open(os.path.join(gpu_out_dir, "parity_ops.jsonl"), "a") as f:
+        f.write(json.dumps(dict(test=name, **kw)) + "\n")
+
+
+def where_bad(a, b, tol):
+    a = np.asarray(a); b = np.asarray(b)
+    d = np.abs(a - b)
+    idx = np.unravel_index(np.argmax(d), d.shape)
+    return f"max|d|={d.max():.3e} at {idx}: got {a[idx]:.6g} want {b[idx]:.6g}; #bad={(d > tol * (np.abs(b).max() + 1e-30)).sum()}/{d.size}"
+
+
+LAYER_IN = {  # layer -> (Hin, Win, channels as multiple: 'x'=3, 'c'=C, 'c15'=1.5C)
+    "GA0": (21, 26, "x"), "GA1": (13, 10, "c"), "GA2": (8, 9, "c"), "GA3": (6, 5, "c"),
+    "GS0": (3, 4, "c"), "GS1": (5, 7, "c"), "GS2": (6, 6, "c"), "GS3": (9, 11, "c"),
+    "HA0": (6, 5, "c"), "HA1": (7, 6, "c"), "HA2": (5, 4, "c"),
+    "HS0": (2, 3, "c"), "HS1": (4, 5, "c"), "HS2": (8, 7, "c15"),
+}
+
+
+def _layer_input(layer, C, B=2, seed=0):
+    Hi, Wi, ch = LAYER_IN[layer]
+    cin = {"x": 3, "c": C, "c15": int(1.5 * C)}[ch]
+    rng = np.random.RandomState(seed + 17 * list(LAYER_IN).index(layer))
+    return rng.standard_normal((B, Hi, Wi, cin)).astype(np.float32)
+
+
+@pytest.mark.parametrize("C", [64, 128, 192])
+@pytest.mark.parametrize("layer", list(LAYER_IN))
+def test_layer_forward(layer, C, gpu_out_dir):
+    """conv / transposed conv / 3x3 conv (+ GDN, IGDN, ReLU) vs torch.nn.functional on
+    asymmetric random kernels and odd sizes (catches flip / transposition / padding errors)."""
+    codec, orc, _, _ = get_codec(C)
+    x = _layer_input(layer, C)
+    want = orc.layer_fwd(layer, x).numpy()
+    got = codec.layer_fwd(layer, x).cpu().numpy()
+    assert got.shape == want.shape
+    e = rel_err(got, want)
+    report(gpu_out_dir, "layer_fwd", layer=layer, C=C, rel_err=e)
+    assert e < 2e-5, f"{layer} C={C}: {where_bad(got, want, 2e-5)}"
+
+
+@pytest.mark.parametrize("C", [64, 192])
+@pytest.mark.parametrize("layer", ["GS0", "GS1", "GS2", "GS3", "HS0", "HS1", "HS2"])
+def test_layer_backward(layer, C, gpu_out_dir):
+    """data-gradient of each synthesis-side layer vs float64 autograd of the oracle."""
+    codec, orc, orc64, _ = get_codec(C)
+    x = _layer_input(layer, C, seed=3)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    out = orc64.layer_fwd(layer, xt)
+    g_out = np.random.RandomState(5).standard_normal(tuple(out.shape)).astype(np.float32)
+    (want,) = torch.autograd.grad(out, xt, torch.tensor(g_out, dtype=torch.float64))
+    got = codec.layer_bwd(layer, x, g_out).cpu().numpy()
+    e = rel_err(got, want.numpy())
+    report(gpu_out_dir, "layer_bwd", layer=layer, C=C, rel_err=e)
+    assert e < 5e-5, f"{layer} C={C}: {where_bad(got, want.numpy(), 5e-5)}"
+
+
+def test_impulse_orientation(gpu_out_dir):
+    """Asymmetric impulse through the transposed conv: a single 1 at one input pixel/channel
+    must reproduce the (un-flipped) kernel slice at out[2i+ky-2, 2j+kx-2]."""
+    C = 64
+    codec, orc, _, w = get_codec(C)
+    x = np.zeros((1, 4, 5, C), np.float32)
+    x[0, 1, 2, 7] = 1.0
+    got = codec.layer_fwd("HS0", x).cpu().numpy()
+    K = w["hs.k0"]
+    want = np.zeros((1, 8, 10, C), np.float32)
+    for ky in range(5):
+        for kx in range(5):
+            oy, ox = 2 * 1 + ky - 2, 2 * 2 + kx - 2
+            if 0 <= oy < 8 and 0 <= ox < 10:
+                want[0, oy, ox] += K[ky, kx, 7, :]
+    want = np.maximum(want + w["hs.b0"], 0)
+    assert rel_err(got, want) < 1e-6, where_bad(got, want, 1e-6)
+
+
+@pytest.mark.parametrize("T", [0.5, 0.2, 0.05])
+def test_sampler(T, gpu_out_dir):
+    """SGA relaxation with injected uniforms: value and Jacobian vs oracle autograd
+    (float64); includes exact integers (fl == ce) and values next to integers (clip active)."""
+    codec, orc, orc64, _ = get_codec(64)
+    rng = np.random.RandomState(0)
+    v = (rng.standard_normal(4096) * 3).astype(np.float32)
+    v[:8] = np.array([0.0, 1.0, -2.0, 3.0, 0.5, -0.5, 1e-6, 1 - 1e-6], np.float32)
+    v[8:16] = np.float32(2.0) + np.array([1e-7, -1e-7, 5e-6, -5e-6, 2e-5, -2e-5, 1e-3, -1e-3], np.float32)
+    u = rng.uniform(1e-6, 1 - 1e-6, (4096, 2)).astype(np.float32)
+    vt = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+    out = SGAOracle.sga_sample(vt, T, torch.tensor(u, dtype=torch.float64))
+    (jac,) = torch.autograd.grad(out.sum(), vt)
+    got_v, got_j = codec.sample(v, u, T)
+    ev = rel_err(got_v.cpu().numpy(), out.detach().numpy())
+    # jacobian: elementwise relative (magnitudes span orders)
+    gj, wj = got_j.cpu().numpy().astype(np.float64), jac.numpy()
+    ej = float(np.max(np.abs(gj - wj) / (np.abs(wj) + 1e-3 * np.abs(wj).max())))
+    report(gpu_out_dir, "sampler", T=T, rel_err_v=ev, rel_err_jac=ej)
+    assert ev < 1e-5
+    assert ej < 2e-3, where_bad(gj, wj, 2e-3)
+
+
+def test_sampler_limit_rounds(gpu_out_dir):
+    """T -> small: v_tilde -> round-to-nearest w.p. -> 1 (SURVEY 8(c) test 4)."""
+    codec, _, _, _ = get_codec(64)
+    rng = np.random.RandomState(1)
+    v = (rng.standard_normal(8192) * 3).astype(np.float32)
+    v = v[np.abs(v - np.round(v)) < 0.3]
+    u = rng.uniform(0.05, 0.95, (v.size, 2)).astype(np.float32)
+    vt, _ = codec.sample(v, u, 0.02)
+    assert np.abs(vt.cpu().numpy() - np.round(v)).max() < 1e-3
+
+
+def test_factorized_likelihood(gpu_out_dir):
+    codec, orc, orc64, _ = get_codec(64)
+    rng = np.random.RandomState(2)
+    v = (rng.standard_normal((3, 5, 4, 64)) * 6).astype(np.float32)
+    vt = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+    p = orc64.eb_likelihood(vt)
+    (dp,) = torch.autograd.grad(p.sum(), vt)
+    gp, gdp = codec.factorized_likelihood(v)
+    e1, e2 = rel_err(gp.cpu().numpy(), p.detach().numpy()), rel_err(gdp.cpu().numpy(), dp.numpy())
+    report(gpu_out_dir, "factorized", rel_err_p=e1, rel_err_dp=e2)
+    assert e1 < 2e-5 and e2 < 1e-4
+    # sum over integers of the box mass ~ 1 per channel (SURVEY 8(c) test 3)
+    ks = np.arange(-400, 401, dtype=np.float32)   # init_scale=10 logistic tails reach far
+    grid = np.repeat(ks[:, None], 64, axis=1)
+    mass, _ = codec.factorized_likelihood(grid)
+    assert np.allclose(mass.cpu().numpy().sum(0), 1.0, atol=1e-3)
+
+
+def test_gaussian_likelihood(gpu_out_dir):
+    codec, orc, orc64, _ = get_codec(64)
+    rng = np.random.RandomState(3)
+    n = 20000
+    y = (rng.standard_normal(n) * 4).astype(np.float32)
+    mu = rng.standard_normal(n).astype(np.float32)
+    sr = (rng.standard_normal(n) * 1.2).astype(np.float32)
+    sr[:100] = -4.0            # sigma below the 0.11 bound
+    y[:50] = mu[:50]           # |y - mu| = 0: sign() = 0
+    yt, mt, st = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (y, mu, sr))
+    # straight max() on sigma for the unit op (no upstream sign): d/dsraw = 0 below the bound
+    sigma = torch.clamp_min(torch.exp(st), 0.11)
+    v = torch.abs(yt - mt)
+    c = 2.0 ** -0.5
+    p = 0.5 * torch.erfc(-c * ((0.5 - v) / sigma)) - 0.5 * torch.erfc(-c * ((-0.5 - v) / sigma))
+    dy, dm, ds = torch.autograd.grad(p.sum(), [yt, mt, st])
+    gp, gdy, gdm, gds = (t.cpu().numpy() for t in codec.gaussian_likelihood(y, mu, sr))
+    errs = dict(p=rel_err(gp, p.detach().numpy()), dy=rel_err(gdy, dy.numpy()),
+                dmu=rel_err(gdm, dm.numpy()), dsr=rel_err(gds, ds.numpy()))
+    report(gpu_out_dir, "gaussian", **errs)
+    assert errs["p"] < 1e-5 and errs["dy"] < 5e-5 and errs["dmu"] < 5e-5 and errs["dsr"] < 5e-5, errs
+    # symmetry p(mu+d) = p(mu-d) and sum_k p = 1
+    d = np.float32(1.37)
+    a, *_ = codec.gaussian_likelihood(mu + d, mu, sr)
+    b, *_ = codec.gaussian_likelihood(mu - d, mu, sr)
+    assert np.allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-9)
+    ks = np.arange(-400, 401, dtype=np.float32)
+    tot, *_ = codec.gaussian_likelihood(ks, np.full_like(ks, 0.3), np.full_like(ks, 1.0))
+    assert abs(float(tot.sum()) - 1.0) < 1e-4
+
+
+def test_lower_bound_truth_table():
+    """math_ops.py:63-76 (oracle side; the kernels' use of it is covered by step parity)."""
+    x = torch.tensor([0.5, 0.5, 2.0, 2.0], requires_grad=True)
+    g = torch.tensor([1.0, -1.0, 1.0, -1.0])
+    (gx,) = torch.autograd.grad(lower_bound(x, 1.0), x, g)
+    assert gx.tolist() == [0.0, -1.0, 1.0, -1.0]
+
+
+def test_adam_bit_exact(gpu_out_dir):
+    """sga_adam vs the f32-pinned restatement of adam.py: bit-for-bit over 50 updates,
+    and vs the committed fixture generated from the reference's own adam.py (rtol 1e-6)."""
+    codec, *_ = get_codec(64)
+    rng = np.random.RandomState(4)
+    n = 10007
+    p0 = rng.standard_normal(n).astype(np.float32)
+    opt = AdamF32(lr=0.005)
+    p_ref = p0.copy()
+    p = torch.tensor(p0, device="cuda")
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for t in range(1, 51):
+        g = (rng.standard_normal(n) * (1e-3 if t % 2 else 3.0)).astype(np.float32)
+        (p_ref,) = opt.update([p_ref], [g])
+        codec.adam(p, torch.tensor(g, device="cuda"), m, v, t, lr=0.005)
+        assert np.array_equal(p.cpu().numpy(), p_ref), f"adam differs at t={t}"
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "adam_reference.npz"))
+    p = torch.tensor(fx["p0"], device="cuda")
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for t in range(1, int(fx["steps"]) + 1):
+        codec.adam(p, torch.tensor(fx["grads"][t - 1], device="cuda"), m, v, t, lr=float(fx["lr"]))
+        if t in fx["checkpoints"]:
+            want = fx[f"p_after_{t}"]
+            assert np.allclose(p.cpu().numpy(), want, rtol=1e-6, atol=1e-7), f"fixture t={t}"

@@ -1,0 +1,189 @@
+"""GPU parity, path level: sga_encode / sga_step_grads / sga_eval / sga_run through the C ABI
+against the CPU oracle on the same seeded inputs and identical (injected or Philox) noise
+(SURVEY.md 8(c) known-answer tests 5, 9).  Includes ragged sizes (not multiples of 16/64:
+the mu/sigma and x_tilde crops of sga.py:123,126-128)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import sga_amd  # noqa: E402
+from oracle import philox  # noqa: E402
+from oracle.sga_oracle import SGAOracle  # noqa: E402
+
+_CACHE = {}
+
+
+def setup(C, B, H, W):
+    from sga_amd.codec import SGACodec
+    key = (C, B, H, W)
+    if key not in _CACHE:
+        w = sga_amd.make_synthetic_weights(C, seed=0)
+        _CACHE[key] = (SGACodec(w, C, B, H, W), SGAOracle(w), SGAOracle(w, dtype=torch.float64))
+    return _CACHE[key]
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def report(gpu_out_dir, name, **kw):
+    with open(os.path.join(gpu_out_dir, "parity_step.jsonl"), "a") as f:
+        f.write(json.dumps(dict(test=name, **kw)) + "\n")
+
+
+def image(B, H, W, seed=0):
+    return np.random.RandomState(seed).rand(B, H, W, 3).astype(np.float32)
+
+
+SHAPES = [(64, 2, 64, 64), (64, 1, 50, 70), (192, 2, 64, 48), (128, 1, 37, 41)]
+
+
+@pytest.mark.parametrize("C,B,H,W", SHAPES)
+def test_encode(C, B, H, W, gpu_out_dir):
+    codec, orc, _ = setup(C, B, H, W)
+    x = image(B, H, W)
+    y, z = codec.encode(x)
+    yo, zo = orc.encode(x)
+    ey, ez = rel_err(y.cpu().numpy(), yo.numpy()), rel_err(z.cpu().numpy(), zo.numpy())
+    report(gpu_out_dir, "encode", C=C, B=B, H=H, W=W, rel_err_y=ey, rel_err_z=ez)
+    assert y.shape == yo.shape and z.shape == zo.shape
+    assert ey < 5e-5 and ez < 1e-4
+
+
+@pytest.mark.parametrize("T", [0.5, 0.15])
+@pytest.mark.parametrize("C,B,H,W", SHAPES)
+def test_step_grads_injected_noise(C, B, H, W, T, gpu_out_dir):
+    """Full-step gradient vs float64 autograd of the oracle (rel err <= 1e-4 of the max
+    gradient) and the logged scalars (sga.py:212)."""
+    codec, orc, orc64 = setup(C, B, H, W)
+    x = image(B, H, W, seed=1)
+    yo, zo = orc.encode(x)
+    rng = np.random.RandomState(9)
+    # move latents off the encoder output a little so floor/ceil neighbours are generic
+    y0 = (yo.numpy() + 0.3 * rng.standard_normal(tuple(yo.shape))).astype(np.float32)
+    z0 = (zo.numpy() + 0.3 * rng.standard_normal(tuple(zo.shape))).astype(np.float32)
+    u_y = rng.uniform(1e-4, 1 - 1e-4, (y0.size, 2)).astype(np.float32)
+    u_z = rng.uniform(1e-4, 1 - 1e-4, (z0.size, 2)).astype(np.float32)
+    lam = 0.01
+    ref = orc64.step(x, y0, z0, T, u_y, u_z, lam)
+    got = codec.step_grads(x, y0, z0, T, lam, u_y=u_y, u_z=u_z)
+    ey = rel_err(got["gy"].cpu().numpy(), ref["gy"].numpy())
+    ez = rel_err(got["gz"].cpu().numpy(), ref["gz"].numpy())
+    report(gpu_out_dir, "step_grads", C=C, B=B, H=H, W=W, T=T, rel_err_gy=ey, rel_err_gz=ez,
+           rd_loss=got["rd_loss"], rd_loss_ref=ref["rd_loss"])
+    assert ey < 1e-4, f"gy rel err {ey}"
+    assert ez < 1e-4, f"gz rel err {ez}"
+    for k in ("rd_loss", "train_mse", "train_bpp"):
+        assert abs(got[k] - ref[k]) <= 2e-5 * abs(ref[k]), (k, got[k], ref[k])
+    assert np.allclose(got["psnr"].cpu().numpy(), ref["psnr"].numpy(), atol=2e-3)
+
+
+def test_step_grads_philox(gpu_out_dir):
+    """Device Philox stream == oracle/philox.py: same gradients without injecting noise."""
+    C, B, H, W = 64, 2, 64, 64
+    codec, orc, orc64 = setup(C, B, H, W)
+    x = image(B, H, W, seed=2)
+    yo, zo = orc.encode(x)
+    seed, it = (0x1234567 << 32) | 0x89ABCDEF, 1234
+    u_y = philox.sga_uniforms(yo.numel(), it, 0, seed)
+    u_z = philox.sga_uniforms(zo.numel(), it, 1, seed)
+    ref = orc64.step(x, yo.numpy(), zo.numpy(), 0.3, u_y, u_z, 0.02)
+    got = codec.step_grads(x, yo.numpy(), zo.numpy(), 0.3, 0.02, seed=seed, it=it)
+    assert rel_err(got["gy"].cpu().numpy(), ref["gy"].numpy()) < 1e-4
+    assert rel_err(got["gz"].cpu().numpy(), ref["gz"].numpy()) < 1e-4
+
+
+def test_loss_scale_sharding(gpu_out_dir):
+    """Shards with loss_scale = 1/B_ref reproduce the un-sharded per-image gradients
+    (SURVEY 8(e)): step on image 0 alone == rows of the 2-image batch."""
+    C, B, H, W = 64, 2, 64, 64
+    codec, orc, _ = setup(C, B, H, W)
+    x = image(B, H, W, seed=3)
+    yo, zo = orc.encode(x)
+    y0, z0 = yo.numpy(), zo.numpy()
+    rng = np.random.RandomState(3)
+    u_y = rng.uniform(1e-4, 1 - 1e-4, (*y0.shape, 2)).astype(np.float32)
+    u_z = rng.uniform(1e-4, 1 - 1e-4, (*z0.shape, 2)).astype(np.float32)
+    full = codec.step_grads(x, y0, z0, 0.4, 0.01, u_y=u_y, u_z=u_z)
+    gy_full = full["gy"].cpu().numpy()
+    part = codec.step_grads(x[:1], y0[:1], z0[:1], 0.4, 0.01, loss_scale=0.5, u_y=u_y[:1], u_z=u_z[:1])
+    assert np.array_equal(part["gy"].cpu().numpy(), gy_full[:1])
+
+
+@pytest.mark.parametrize("C,B,H,W", SHAPES)
+def test_eval_rounded_latents(C, B, H, W, gpu_out_dir):
+    from sga_amd.codec import metrics_to_dict
+    codec, orc, _ = setup(C, B, H, W)
+    x = image(B, H, W, seed=4)
+    yo, zo = orc.encode(x)
+    y_hat, z_hat = np.round(yo.numpy()), np.round(zo.numpy())
+    want = orc.evaluate(x, y_hat, z_hat)
+    got = metrics_to_dict(codec.evaluate(x, y_hat, z_hat))
+    report(gpu_out_dir, "eval", C=C, H=H, W=W, bpp=got["est_bpp"].tolist(), bpp_ref=want["est_bpp"].tolist(),
+           psnr=got["psnr"].tolist(), psnr_ref=want["psnr"].tolist())
+    for k in ("est_bpp", "est_y_bpp", "est_z_bpp"):
+        assert np.allclose(got[k], want[k], rtol=2e-5), k
+    assert np.allclose(got["mse"], want["mse"], rtol=1e-3)       # rounding of x_tilde at .5 ties
+    assert np.allclose(got["psnr"], want["psnr"], atol=5e-3)
+
+
+def test_base_compress(gpu_out_dir):
+    """cfg 1 (mbt2018.py compress, estimated-rate path)."""
+    from sga_amd.codec import metrics_to_dict
+    C, B, H, W = 64, 1, 50, 70
+    codec, orc, _ = setup(C, B, H, W)
+    x = image(B, H, W, seed=5)
+    y_hat, z_hat, met = codec.base_compress(x)
+    yo, zo, want = orc.base_compress(x)
+    # rounding can flip at exact .5 ties only: allow a handful of off-by-one latents
+    ny = np.abs(y_hat.cpu().numpy() - yo.numpy()) > 1e-3
+    assert ny.mean() < 1e-3
+    got = metrics_to_dict(met)
+    assert np.allclose(got["est_bpp"], want["est_bpp"], rtol=2e-3)
+    assert np.allclose(got["psnr"], want["psnr"], atol=0.02)
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_run_short_vs_oracle(graph, gpu_out_dir, monkeypatch):
+    """40 fused iterations (Philox noise, on-device Adam, hipGraph replay or eager launches)
+    vs the oracle loop: latents stay within float32 drift, per-step trace agrees."""
+    from sga_amd.codec import SGACodec, metrics_to_dict
+    C, B, H, W = 64, 2, 64, 64
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    monkeypatch.setenv("SGA_NO_GRAPH", "0" if graph else "1")
+    codec = SGACodec(w, C, B, H, W)
+    orc = SGAOracle(w)
+    x = image(B, H, W, seed=6)
+    its = 40
+    # t0 = 10: temperature anneals within the short run (utils.py:166-170)
+    y_hat, z_hat, met, tr = codec.run(x, 0.01, its=its, t0=10, annealing_rate=0.02, seed=11, trace=True)
+    yo, zo, mo, tro = orc.run(x, 0.01, its=its, t0=10, r=0.02, seed=11, trace=True)
+    tr = tr.cpu().numpy()
+    report(gpu_out_dir, "run_short", graph=graph, trace_gpu_last=tr[-1].tolist(), trace_ref_last=tro[-1].tolist(),
+           max_trace_rel=float(np.abs(tr / tro - 1).max()))
+    assert np.allclose(tr[:, :3], tro[:, :3], rtol=2e-3), np.abs(tr / tro - 1).max(0)
+    frac_diff = float((y_hat.cpu().numpy() != yo).mean())
+    assert frac_diff < 5e-3, f"{frac_diff} of rounded latents differ"
+    got = metrics_to_dict(met)
+    assert np.allclose(got["est_bpp"], mo["est_bpp"], rtol=5e-3)
+    assert np.allclose(got["psnr"], mo["psnr"], atol=0.05)
+    codec.close()
+
+
+def test_run_deterministic(gpu_out_dir):
+    """Same seed -> bit-identical rounded latents (no atomics on the gradient path)."""
+    C, B, H, W = 64, 2, 64, 64
+    codec, _, _ = setup(C, B, H, W)
+    x = image(B, H, W, seed=7)
+    a = codec.run(x, 0.01, its=25, seed=3)
+    b = codec.run(x, 0.01, its=25, seed=3)
+    c = codec.run(x, 0.01, its=25, seed=4)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert not torch.equal(a[0], c[0])
