@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec for a complete 2000-step SGA run (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: sga_run on a batch of 8 synthetic
+256x256x3 images, num_filters=192, lambda=0.01 -- encode + 2000 x (Gumbel sample, forward,
+data-gradients, Adam) + round + eval (BASELINE.json configs[1]; reference loop sga.py:207-247).
+Images shard across ranks (one process per GPU, each its own batch of 8: weak scaling); the only
+collective is the final all_gather of the [8,7] metrics over RCCL.
+
+Inputs are resident in HBM before the timed region.  The timed region replays the captured
+hipGraph of the step sequence; afterwards a short eager, hipEvent-instrumented run gives the
+dominant kernel's average duration for the `roofline` object (peak: 157.3 TFLOP/s fp32 MFMA,
+MI355X_MICROARCH.md), and -- at N=1 -- the CPU oracle is timed on the host cores for
+`cpu_baseline` (a PyTorch-CPU port of the same graph; the TF1 reference cannot run here).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table
+
+
+def gflop_per_image_step(H, W, C):
+    """useful MACs fwd + data-grad, 2 FLOP/MAC, per image per SGA step."""
+    h, w = -(-H // 16), -(-W // 16)
+    hz, wz = -(-(-(-h // 2)) // 2), -(-(-(-w // 2)) // 2)
+    C15 = int(1.5 * C)
+    f = 4 * (h * w * (25 * C * C * (1 + 4 + 16) + 25 * 3 * C * 64 + C * C * (4 + 16 + 64))
+             + hz * wz * (25 * C * C + 4 * 25 * C * C15 + 16 * 9 * C15 * 2 * C))
+    return f / 1e9
+
+
+def cpu_baseline(C, H, W, lam, budget_s=15.0):
+    """Oracle (kind "port") timed on the host cores: B=1, homogeneous steps, extrapolated x2000."""
+    import sga_amd
+    from oracle.sga_oracle import SGAOracle
+    from oracle import philox
+    ncpu = os.cpu_count() or 1
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    orc = SGAOracle(w)
+    x = np.random.RandomState(0).rand(1, H, W, 3).astype(np.float32)
+    y, z = orc.encode(x)
+    y, z = y.numpy(), z.numpy()
+    u_y = philox.sga_uniforms(y.size, 0, 0, 0)
+    u_z = philox.sga_uniforms(z.size, 0, 1, 0)
+
+    def timed(nsteps):
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            orc.step(x, y, z, 0.5, u_y, u_z, lam)
+        return (time.perf_counter() - t0) / nsteps
+
+    # oneDNN does not scale to every core of a big host at B=1: pick the fastest thread count
+    best_t, cores = None, 1
+    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(nt)
+        timed(1)
+        t = timed(2)
+        if best_t is None or t < best_t:
+            best_t, cores = t, nt
+    torch.set_num_threads(cores)
+    n = max(3, min(400, int(budget_s / best_t)))
+    el = timed(n) * n
+    s_per_step = el / n
+    return dict(value=1.0 / (2000.0 * s_per_step), unit="images/sec", cores=cores, kind="port",
+                sample=f"{n} SGA steps of the PyTorch-CPU oracle at B=1 {H}x{W} C={C} "
+                       f"({s_per_step * 1e3:.1f} ms/step), extrapolated x2000 steps/image")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--num_filters", type=int, default=192)
+    ap.add_argument("--its", type=int, default=2000)
+    ap.add_argument("--lmbda", type=float, default=0.01)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device(f"cuda:{local_rank}"))
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    import sga_amd
+    from sga_amd.codec import SGACodec
+    B, H, W, C = args.batch, args.size, args.size, args.num_filters
+    weights = sga_amd.make_synthetic_weights(C, seed=0)
+    codec = SGACodec(weights, C, B, H, W, device=device)
+    gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    x = torch.rand(B, H, W, 3, generator=gen).to(device)     # resident in HBM before timing
+
+    def one_step(seed):
+        y_hat, z_hat, met, _ = codec.run(x, args.lmbda, its=args.its, seed=seed)
+        if dist is not None:     # result gather: the only collective on this path
+            out = [torch.empty_like(met) for _ in range(world)]
+            dist.all_gather(out, met)
+            met = torch.cat(out, 0)
+        return met
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    t0 = time.perf_counter()
+    met = None
+    for i in range(args.steps):
+        met = one_step(100 + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    n_images = world * B * args.steps
+    value = n_images / elapsed
+
+    # ---- roofline of the dominant kernel: live hipEvent timing over eager launches ----------
+    roofline = None
+    kernels = []
+    if not args.no_kernel_profile and rank == 0:
+        prof_its = min(args.its, 60)
+        codec.profile_begin()
+        codec.run(x, args.lmbda, its=prof_its, seed=7, metrics=False)
+        kernels = sorted(codec.profile_end(), key=lambda k: -k["ms_total"])
+        if kernels:
+            k = kernels[0]
+            achieved = k["flops_total"] / (k["ms_total"] * 1e-3) / 1e12
+            roofline = dict(bound="mfma", kernel=k["name"], achieved=round(achieved, 3),
+                            peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                            avg_launch_us=round(1e3 * k["ms_total"] / k["launches"], 2),
+                            gflop_per_launch=round(k["flops_total"] / k["launches"] / 1e9, 4),
+                            launches=k["launches"], traffic=None)
+    tf_per_image = gflop_per_image_step(H, W, C) * args.its / 1e3
+    path_frac = value / world * tf_per_image / FP32_MFMA_PEAK_TFLOPS
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(C, H, W, args.lmbda)
+
+    if rank == 0:
+        m = met.detach().cpu().numpy()
+        line = {
+            "metric": "images/sec for 2000-step SGA (num_filters=192, 256x256) + final BPP/PSNR match",
+            "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"sga.py {args.its}-step SGA, num_filters={C}, lambda={args.lmbda}, "
+                                   f"batch of {B} synthetic {H}x{W} images per GPU",
+                       "images_per_step": world * B, "sga_iterations": args.its,
+                       "weights": "synthetic (make_synthetic_weights seed 0)",
+                       "parallelism": f"images sharded over {world} GPU(s), RCCL all_gather of metrics"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "path_frac_of_fp32_mfma_peak": round(path_frac, 4),
+            "tflop_per_image": round(tf_per_image, 3),
+            "final_est_bpp_mean": float(np.mean(m[:, 4])), "final_psnr_mean": float(np.mean(m[:, 1])),
+            "kernels": [dict(name=k["name"], launches=k["launches"], ms=round(k["ms_total"], 3),
+                             tflops=round(k["flops_total"] / (k["ms_total"] * 1e-3) / 1e12, 2))
+                        for k in kernels],
+        }
+        if cpu:
+            line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,16 @@ SYMBOLS = {
     "sga_op_gaussian_likelihood": (_I, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
 }
 
+
+
+class SgaKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("ms_total", C.c_double),
+                ("flops_total", C.c_double)]
+
+
+SYMBOLS["sga_profile_begin"] = (_I, [_P])
+SYMBOLS["sga_profile_end"] = (_I, [_P, C.POINTER(SgaKernelStat), _I, C.POINTER(_I)])
+
 _lib = None
 
 

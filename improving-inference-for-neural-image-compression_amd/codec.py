@@ -196,6 +196,20 @@ class SGACodec:
         self._exit()
         return y_hat, z_hat, met
 
+    # ---- measurement ---------------------------------------------------------------------------
+    def profile_begin(self):
+        """Time every MFMA convolution launch with hipEvents until profile_end (sga_run goes eager)."""
+        self._chk(self.lib.sga_profile_begin(self.handle), "sga_profile_begin")
+
+    def profile_end(self):
+        """-> list of dicts {name, launches, ms_total, flops_total} per kernel symbol."""
+        arr = (_lib.SgaKernelStat * 64)()
+        n = C.c_int(0)
+        self._chk(self.lib.sga_profile_end(self.handle, arr, 64, C.byref(n)), "sga_profile_end")
+        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches),
+                     ms_total=float(arr[i].ms_total), flops_total=float(arr[i].flops_total))
+                for i in range(min(n.value, 64))]
+
     # ---- operator surface (unit parity) --------------------------------------------------------
     def layer_fwd(self, layer: str, inp):
         inp = self._t(inp)

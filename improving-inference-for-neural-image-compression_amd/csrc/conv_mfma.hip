@@ -17,6 +17,8 @@
 //
 // f32 MFMA is a bitwise f32 fmaf chain (cdna_hip_programming.md s3), so results match an
 // f32 reference to summation-order rounding; no reduced precision anywhere.
+#include <cstdio>
+
 #include "sga_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -281,7 +283,19 @@ int conv_pick_bn(int cout, int epi) {
   return best;
 }
 
-int conv_tile_m(int bn) { (void)bn; return 128; }
+void conv_kernel_name(const ConvArgs& a, char* out, int len) {
+  const int bn = a.Npad / a.ntiles_n;
+  int tn = 0, wm = 2, wn = 2, tm = 2;
+  switch (bn) {
+    case 192: tn = 3; break;
+    case 256: tn = 4; break;
+    case 64: tn = 1; break;
+    case 96: tn = 3; wn = 1; break;
+    case 32: tn = 1; tm = 1; wm = 4; wn = 1; break;
+  }
+  snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
+           a.smallc ? "true" : "false");
+}
 
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
   const int bn = a.Npad / a.ntiles_n;

@@ -12,7 +12,6 @@ namespace {
 constexpr float kEps = 1e-5f;          // sga.py:30
 constexpr float kLikBound = 1e-9f;     // sga.py:28 / tfc likelihood_bound
 constexpr float kScaleMin = 0.11f;     // sga.py:24
-constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 constexpr float kInvSqrt2Pi = 0.3989422804014327f;
 

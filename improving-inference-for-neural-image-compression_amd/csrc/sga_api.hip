@@ -94,6 +94,11 @@ struct sga_handle {
   hipGraphExec_t graph_exec = nullptr;
   int graph_B = 0, graph_H = 0, graph_W = 0;
   int use_graph = 1;
+
+  // ---- per-kernel profiling (sga_profile_begin/end) ----
+  struct ProfRec { hipEvent_t a, b; double flops; char name[64]; };
+  bool profiling = false;
+  std::vector<ProfRec> prof;
 };
 
 namespace {
@@ -114,6 +119,24 @@ namespace {
     const int _s = (expr);           \
     if (_s != SGA_OK) return _s;     \
   } while (0)
+
+// every MFMA convolution goes through here (so it can be timed)
+int conv_launch(sga_handle* h, const ConvArgs& a, hipStream_t st) {
+  if (!h->profiling) {
+    HIPCHK(h, launch_conv(a, st));
+    return SGA_OK;
+  }
+  sga_handle::ProfRec r;
+  r.flops = a.flops;
+  conv_kernel_name(a, r.name, sizeof(r.name));
+  HIPCHK(h, hipEventCreate(&r.a));
+  HIPCHK(h, hipEventCreate(&r.b));
+  HIPCHK(h, hipEventRecord(r.a, st));
+  HIPCHK(h, launch_conv(a, st));
+  HIPCHK(h, hipEventRecord(r.b, st));
+  h->prof.push_back(r);
+  return SGA_OK;
+}
 
 int dev_alloc(sga_handle* h, void** p, size_t bytes) {
   if (bytes == 0) bytes = 256;
@@ -314,8 +337,8 @@ int deconv_fwd(sga_handle* h, const PackedConv& pc, const float* bias, const flo
   a.Hin = Hi; a.Win = Wi; a.Hout = 2 * Hi; a.Wout = 2 * Wi;
   a.s_in = 1; a.s_out = 2; a.epi = epi;
   taps_deconv5_s2(a);
-  HIPCHK(h, launch_conv(a, st));
-  return SGA_OK;
+  a.flops = 2.0 * B * Hi * Wi * 25.0 * pc.Kc * pc.N;
+  return conv_launch(h, a, st);
 }
 
 // stride-2 5x5 conv over `in` [B,Hi,Wi,K] -> [B,Ho,Wo,N]; used for analysis forward and for the
@@ -327,8 +350,8 @@ int conv5s2(sga_handle* h, const PackedConv& pc, const float* bias, const float*
   a.Hin = Hi; a.Win = Wi; a.Hout = Ho; a.Wout = Wo;
   a.s_in = 2; a.s_out = 1; a.epi = epi;
   taps_conv5_s2(a);
-  HIPCHK(h, launch_conv(a, st));
-  return SGA_OK;
+  a.flops = 2.0 * B * Ho * Wo * 25.0 * pc.Kc * pc.N;
+  return conv_launch(h, a, st);
 }
 
 int conv3(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int in_cs, int B,
@@ -338,8 +361,8 @@ int conv3(sga_handle* h, const PackedConv& pc, const float* bias, const float* i
   a.Hin = Hi; a.Win = Wi; a.Hout = Hi; a.Wout = Wi;
   a.epi = epi;
   taps_conv3(a, true_conv);
-  HIPCHK(h, launch_conv(a, st));
-  return SGA_OK;
+  a.flops = 2.0 * B * Hi * Wi * 9.0 * pc.Kc * pc.N;
+  return conv_launch(h, a, st);
 }
 
 // GDN / IGDN forward on u [B,Hh,Ww,C]: out = u * sqrt(n) (inverse) or u / sqrt(n); s_out = sqrt(n)
@@ -350,8 +373,8 @@ int gdn_fwd(sga_handle* h, const PackedConv& pc, const float* beta, const float*
   a.Hin = Hh; a.Win = Ww; a.Hout = Hh; a.Wout = Ww;
   a.pro = PRO_SQUARE; a.epi = inverse ? EPI_IGDN : EPI_GDN;
   taps_single(a);
-  HIPCHK(h, launch_conv(a, st));
-  return SGA_OK;
+  a.flops = 2.0 * B * Hh * Ww * (double)pc.Kc * pc.N;
+  return conv_launch(h, a, st);
 }
 
 // IGDN backward: g_u = g_v * s + u * (gamma . (g_v * u / s))
@@ -362,8 +385,8 @@ int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float*
   a.Hin = Hh; a.Win = Ww; a.Hout = Hh; a.Wout = Ww;
   a.pro = PRO_IGDN_BWD; a.epi = EPI_IGDN_BWD;
   taps_single(a);
-  HIPCHK(h, launch_conv(a, st));
-  return SGA_OK;
+  a.flops = 2.0 * B * Hh * Ww * (double)pc.Kc * pc.N;
+  return conv_launch(h, a, st);
 }
 
 // C->3 transposed conv (combined phases): [B,Hi,Wi,C] -> out [B,Ho,Wo,3] cropped to (Ho,Wo)
@@ -374,8 +397,8 @@ int deconv_to3(sga_handle* h, const PackedConv& pc, const float* bias, const flo
   a.Hin = Hi; a.Win = Wi; a.Hout = Ho; a.Wout = Wo;
   a.Cout = 12; a.out_cs = 3; a.epi = EPI_SHUFFLE3;
   taps_shuffle3(a);
-  HIPCHK(h, launch_conv(a, st));
-  return SGA_OK;
+  a.flops = 2.0 * B * Hi * Wi * 25.0 * pc.Kc * 3.0;
+  return conv_launch(h, a, st);
 }
 
 // 5x5/2 conv over the zero-bordered 3-channel image `pad` [B,Hp,Wp,3] -> [B,Ho,Wo,C]
@@ -386,8 +409,8 @@ int conv_smallc(sga_handle* h, const PackedConv& pc, const float* bias, const fl
   a.Hin = Hp; a.Win = Wp; a.Hout = Ho; a.Wout = Wo;
   a.s_in = 2; a.smallc = 1; a.epi = EPI_BIAS;
   taps_smallc(a);
-  HIPCHK(h, launch_conv(a, st));
-  return SGA_OK;
+  a.flops = 2.0 * B * Ho * Wo * 75.0 * pc.N;
+  return conv_launch(h, a, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -502,8 +525,9 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
 }
 
 void free_all(sga_handle* h) {
-  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
-  for (void* p : h->owned) hipFree(p);
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (void* p : h->owned) (void)hipFree(p);
   h->owned.clear();
 }
 
@@ -639,7 +663,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
 
 int sga_destroy(sga_handle* h) {
   if (!h) return SGA_ERR_BAD_ARG;
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
   free_all(h);
   delete h;
   return SGA_OK;
@@ -765,9 +789,9 @@ int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, fl
     };
 
     bool graphed = false;
-    if (h->use_graph) {
+    if (h->use_graph && !h->profiling) {
       if (!h->graph_exec || h->graph_B != B || h->graph_H != H || h->graph_W != W) {
-        if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
           const int rc = enqueue_step(st);
@@ -778,7 +802,7 @@ int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, fl
           } else {
             h->graph_exec = nullptr;
           }
-          if (graph) hipGraphDestroy(graph);
+          if (graph) (void)hipGraphDestroy(graph);
         }
         (void)hipGetLastError();
       }
@@ -931,6 +955,43 @@ int sga_op_gaussian_likelihood(sga_handle* h, const float* y, const float* mu,
                                float* dp_dmu, float* dp_dsraw, void* stream) {
   if (!h || !y || !mu || !sigma_raw || n <= 0) return SGA_ERR_BAD_ARG;
   HIPCHK(h, launch_gaussian_op(y, mu, sigma_raw, n, p, dp_dy, dp_dmu, dp_dsraw, (hipStream_t)stream));
+  return SGA_OK;
+}
+
+int sga_profile_begin(sga_handle* h) {
+  if (!h) return SGA_ERR_BAD_ARG;
+  for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  h->prof.clear();
+  h->profiling = true;
+  return SGA_OK;
+}
+
+int sga_profile_end(sga_handle* h, sga_kernel_stat* out, int max_out, int* n_out) {
+  if (!h || !n_out) return SGA_ERR_BAD_ARG;
+  h->profiling = false;
+  HIPCHK(h, hipDeviceSynchronize());
+  std::vector<sga_kernel_stat> agg;
+  for (auto& r : h->prof) {
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, r.a, r.b));
+    size_t k = 0;
+    for (; k < agg.size(); ++k)
+      if (strncmp(agg[k].name, r.name, sizeof(agg[k].name)) == 0) break;
+    if (k == agg.size()) {
+      sga_kernel_stat s0;
+      memset(&s0, 0, sizeof(s0));
+      strncpy(s0.name, r.name, sizeof(s0.name) - 1);
+      agg.push_back(s0);
+    }
+    agg[k].launches += 1;
+    agg[k].ms_total += ms;
+    agg[k].flops_total += r.flops;
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  h->prof.clear();
+  *n_out = (int)agg.size();
+  for (int k = 0; k < (int)agg.size() && k < max_out && out; ++k) out[k] = agg[k];
   return SGA_OK;
 }
 

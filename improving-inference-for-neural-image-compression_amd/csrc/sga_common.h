@@ -37,8 +37,9 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 __host__ __device__ inline float bits_to_uniform(uint32_t b) {
-  // ((b >> 8) + 0.5) * 2^-24: strictly inside (0,1), exact in f32
-  return ((float)(b >> 8) + 0.5f) * 5.9604644775390625e-08f;
+  // ((b >> 9) + 0.5) * 2^-23: 23 random bits so that +0.5 is exactly representable in f32
+  // (a 24-bit mantissa): u in [2^-24, 1 - 2^-24], never 0 or 1 (log(-log u) stays finite)
+  return ((float)(b >> 9) + 0.5f) * 1.1920928955078125e-07f;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -74,6 +75,7 @@ struct ConvArgs {
   int nphase, tiles_per_phase, ntiles_n;
   int smallc;              // 1: `in` is a zero-padded 3-channel image [B,Hin,Win,3], 5x5/2 conv
   int pro, epi;
+  double flops;            // algorithmic flops of this launch (profiling only)
   ConvPhase ph[4];
   ConvTap taps[28];
 };
@@ -82,3 +84,5 @@ struct ConvArgs {
 int launch_conv(const ConvArgs& a, hipStream_t stream);
 // tile sizes chosen for an output width (host-side, also used to size Npad when packing)
 int conv_pick_bn(int cout, int epi);
+// kernel symbol (as rocprofv3 prints it) that launch_conv will use for these args
+void conv_kernel_name(const ConvArgs& a, char* out, int len);

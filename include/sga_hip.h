@@ -150,6 +150,21 @@ int sga_op_gaussian_likelihood(sga_handle* h, const float* y, const float* mu,
                                float* p, float* dp_dy, float* dp_dmu, float* dp_dsraw,
                                void* stream);
 
+/* ---- measurement: per-kernel hipEvent timing of the convolution launches -------------------
+ * Between sga_profile_begin and sga_profile_end every MFMA convolution launch issued through
+ * this handle is bracketed by a hipEvent pair on its own stream (sga_run then launches eagerly
+ * instead of replaying its hipGraph).  sga_profile_end synchronises and returns one row per
+ * kernel symbol: launches, summed duration, summed ALGORITHMIC flops (useful MACs x 2, no
+ * zero-stuffed taps, no channel padding). */
+typedef struct sga_kernel_stat {
+  char name[64];          /* kernel symbol as rocprofv3 prints it, e.g. conv_mfma_kernel<2,3,2,2,0,false> */
+  int64_t launches;
+  double ms_total;
+  double flops_total;
+} sga_kernel_stat;
+int sga_profile_begin(sga_handle* h);
+int sga_profile_end(sga_handle* h, sga_kernel_stat* out, int max_out, int* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ Counter layout (one Philox call per latent element):
     ctr = (elem_idx_lo, elem_idx_hi, step, stream)   stream: 0 = y, 1 = z
     key = (seed_lo, seed_hi)
 Outputs [0], [1] become the two uniforms (down, up) of the element via
-    u = ((bits >> 8) + 0.5) * 2^-24      in (0, 1)
+    u = ((bits >> 9) + 0.5) * 2^-23      in [2^-24, 1 - 2^-24]
 (the counterpart of tfp's U(tiny, 1) draw in RelaxedOneHotCategorical.sample).
 """
 import numpy as np
@@ -48,8 +48,9 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def bits_to_uniform(bits):
-    """uint32 -> float32 in (0,1): ((bits >> 8) + 0.5) * 2^-24 (exact in f32)."""
-    return ((bits >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
+    """uint32 -> float32 in (0,1): ((bits >> 9) + 0.5) * 2^-23.  23 random bits so that the
+    +0.5 is exact in f32 (24-bit mantissa): u in [2^-24, 1 - 2^-24], never 0 or 1."""
+    return ((bits >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
 
 
 def sga_uniforms(n_elems, step, stream, seed):
