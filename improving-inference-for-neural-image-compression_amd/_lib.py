@@ -44,6 +44,7 @@ class SgaWeights(C.Structure):
 # every symbol include/sga_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _F = C.c_float
+_D = C.c_double
 _I = C.c_int
 _I64 = C.c_int64
 SYMBOLS = {
@@ -55,8 +56,8 @@ SYMBOLS = {
     "sga_encode": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "sga_step_grads": (_I, [_P, _P, _I, _I, _I, _P, _P, _F, _F, _F, C.c_uint64, C.c_uint32,
                             _P, _P, _P, _P, _P, _P, _P]),
-    "sga_adam": (_I, [_P, _P, _P, _P, _P, _I64, _I, _F, _F, _F, _F, _P]),
-    "sga_run": (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _F, _F, _I, _F, C.c_uint64,
+    "sga_adam": (_I, [_P, _P, _P, _P, _P, _I64, _I, _D, _D, _D, _D, _P]),
+    "sga_run": (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _D, _D, _I, _D, C.c_uint64,
                      _P, _P, _P, _P, _P, _P, _P]),
     "sga_eval": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "sga_base_compress": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -51,6 +51,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
   const int chunk = tid & 7, lrow = tid >> 3;
 
   int bid = blockIdx.x;
+  int split = 0;
+  if (a.ksplit > 1) {
+    const int tiles_total = a.nphase * a.tiles_per_phase * a.ntiles_n;
+    split = bid / tiles_total;
+    bid -= split * tiles_total;
+  }
   const int nt = bid % a.ntiles_n;
   bid /= a.ntiles_n;
   const int phase = bid / a.tiles_per_phase;
@@ -129,15 +135,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-  const int nsteps = ph.ntaps * (a.Cin / BK);
-  int tapi = 0, ci0 = 0;
-  gload(0, 0);
+  const int nchunk = a.Cin / BK;
+  const int nsteps_all = ph.ntaps * nchunk;
+  int k_begin = 0, k_end = nsteps_all;
+  if (a.ksplit > 1) {
+    k_begin = (int)((long long)split * nsteps_all / a.ksplit);
+    k_end = (int)((long long)(split + 1) * nsteps_all / a.ksplit);
+  }
+  int tapi = k_begin / nchunk, ci0 = (k_begin - tapi * nchunk) * BK;
+  if (k_begin < k_end) gload(tapi, ci0);
 
   const int arow = (wm * TM) * 32 + (lane & 31);
   const int brow = (wn * TN) * 32 + (lane & 31);
   const int koff = (lane >> 5) * 4;
 
-  for (int ks = 0; ks < nsteps; ++ks) {
+  for (int ks = k_begin; ks < k_end; ++ks) {
     // ---- staged registers -> LDS (prologue transform fused here) ----------------------
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
     // ---- prefetch the next K-step while this one is multiplied ------------------------
     ci0 += BK;
     if (ci0 >= a.Cin) { ci0 = 0; ++tapi; }
-    if (ks + 1 < nsteps) gload(tapi, ci0);
+    if (ks + 1 < k_end) gload(tapi, ci0);
 
     // ---- 32 k's = 4 x (float4 fragment -> 4 MFMAs per output sub-tile) -----------------
 #pragma unroll
@@ -180,7 +192,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
 
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)
   const int half = lane >> 5, col = lane & 31;
-  const int epi = a.epi;
+  const int epi = a.ksplit > 1 ? -1 : a.epi;      // split-K: raw partial sums, epilogue in the reduce
+  float* const outp = a.ksplit > 1 ? a.part + (size_t)split * a.slab : a.out;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -240,9 +253,32 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
           default:
             break;
         }
-        a.out[o] = v;
+        outp[o] = v;
       }
     }
+  }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long long slab,
+                                     long long n4, int cout, int epi,
+                                     const float* __restrict__ bias, const float* __restrict__ aux0,
+                                     float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    f32x4 acc = ld4(part + e);
+    for (int s = 1; s < ksplit; ++s) acc += ld4(part + (size_t)s * slab + e);   // fixed order
+    const int c = (int)(e % cout);
+    if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && bias) acc += ld4(bias + c);
+    if (epi == EPI_BIAS_RELU) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], 0.f);
+    } else if (epi == EPI_RELU_MASK) {
+      const f32x4 m = ld4(aux0 + e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = m[k] > 0.f ? acc[k] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(out + e) = acc;
   }
 }
 
@@ -251,7 +287,7 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const size_t lds = (size_t)(BM + BN) * LDK * sizeof(float);
-  const int grid = a.nphase * a.tiles_per_phase * a.ntiles_n;
+  const int grid = a.nphase * a.tiles_per_phase * a.ntiles_n * (a.ksplit > 1 ? a.ksplit : 1);
   if (grid <= 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC>), dim3(grid), dim3(NT), lds,
                      stream, a);
@@ -295,6 +331,18 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
   }
   snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
            a.smallc ? "true" : "false");
+}
+
+int launch_splitk_reduce(const float* part, int ksplit, long long slab, long long n, int cout,
+                         int epi, const float* bias, const float* aux0, float* out,
+                         hipStream_t stream) {
+  const long long n4 = n / 4;
+  long long g = (n4 + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, part, ksplit,
+                     slab, n4, cout, epi, bias, aux0, out);
+  return (int)hipGetLastError();
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t stream) {

@@ -540,12 +540,12 @@ int launch_adam_latent(float* p, const float* ga, const float* gb, const float* 
   LAUNCH_RET();
 }
 
-int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1,
-                float b2, float eps, hipStream_t s) {
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, double b1,
+                double b2, double eps, hipStream_t s) {
   // adam.py:44-45: (1. - beta) is formed in double, then cast to the array dtype (float32)
-  const float omb1 = (float)(1.0 - (double)b1), omb2 = (float)(1.0 - (double)b2);
-  hipLaunchKernelGGL(k_adam, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, omb1, b2,
-                     omb2, eps);
+  const float omb1 = (float)(1.0 - b1), omb2 = (float)(1.0 - b2);
+  hipLaunchKernelGGL(k_adam, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, n, lr_t, (float)b1,
+                     omb1, (float)b2, omb2, (float)eps);
   LAUNCH_RET();
 }
 

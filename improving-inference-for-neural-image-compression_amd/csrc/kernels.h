@@ -47,8 +47,8 @@ int launch_combine_grad(const float* ga, const float* gb, const float* jac, floa
                         hipStream_t s);
 int launch_adam_latent(float* p, const float* ga, const float* gb, const float* jac, float* m,
                        float* v, int64_t n, const StepCtx* ctx, hipStream_t s);
-int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1,
-                float b2, float eps, hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, double b1,
+                double b2, double eps, hipStream_t s);
 
 // ctx management
 int launch_set_ctx(StepCtx* ctx, int it, int its, float T, float lr_t, float lambda,

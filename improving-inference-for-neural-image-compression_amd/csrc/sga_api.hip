@@ -83,6 +83,7 @@ struct sga_handle {
   Buf gA, gB, g_yt_dist, g_yt_rate;
   Buf scratch;                   // scalars[4] + psnr[max_batch] + metrics[max_batch*7]
   Buf trace, Ttab, lrtab;
+  Buf part;                      // split-K partial slabs
   ImgSums* sums = nullptr;
   StepCtx* ctx = nullptr;
   std::vector<float> hT, hLr;    // host tables (kept alive across the async upload)
@@ -98,6 +99,9 @@ struct sga_handle {
   // ---- per-kernel profiling (sga_profile_begin/end) ----
   struct ProfRec { hipEvent_t a, b; double flops; char name[64]; };
   bool profiling = false;
+  bool no_splitk = false;          // SGA_NO_SPLITK=1
+  bool profile_by_layer = false;   // SGA_PROFILE_BY_LAYER=1: aggregate by call site instead of symbol
+  const char* cur_tag = "";
   std::vector<ProfRec> prof;
 };
 
@@ -120,21 +124,59 @@ namespace {
     if (_s != SGA_OK) return _s;     \
   } while (0)
 
-// every MFMA convolution goes through here (so it can be timed)
-int conv_launch(sga_handle* h, const ConvArgs& a, hipStream_t st) {
-  if (!h->profiling) {
-    HIPCHK(h, launch_conv(a, st));
-    return SGA_OK;
+// Split-K factor for a launch whose tile grid under-fills the chip (256 CUs): spread the K walk
+// of each tile over S workgroups so that ~2 workgroups per CU are resident and the serial
+// K-chain per workgroup is S times shorter (deterministic slab reduce afterwards).
+int pick_ksplit(const sga_handle* h, const ConvArgs& a) {
+  if (h->no_splitk || a.smallc || a.pro != PRO_NONE) return 1;
+  if (a.epi != EPI_BIAS && a.epi != EPI_BIAS_RELU && a.epi != EPI_RELU_MASK) return 1;
+  if (a.out_coff != 0 || a.out_cs != a.Cout || (a.Cout & 3)) return 1;
+  const int blocks = a.nphase * a.tiles_per_phase * a.ntiles_n;
+  if (blocks > 256 || (blocks == 256 && a.nphase == 1)) return 1;
+  int min_steps = 1 << 30;
+  for (int p = 0; p < a.nphase; ++p) {
+    const int st = a.ph[p].ntaps * (a.Cin / 32);
+    if (st < min_steps) min_steps = st;
   }
+  int S = 512 / blocks;
+  if (S > min_steps / 2) S = min_steps / 2;      // at least 2 K-steps per split
+  const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
+  const long long cap = (long long)h->part.cap / n_out;
+  if (S > cap) S = (int)cap;
+  return S < 2 ? 1 : S;
+}
+
+// every MFMA convolution goes through here (so it can be timed)
+int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st) {
+  a.ksplit = pick_ksplit(h, a);
+  const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
+  if (a.ksplit > 1) { a.part = h->part.p; a.slab = n_out; }
   sga_handle::ProfRec r;
-  r.flops = a.flops;
-  conv_kernel_name(a, r.name, sizeof(r.name));
-  HIPCHK(h, hipEventCreate(&r.a));
-  HIPCHK(h, hipEventCreate(&r.b));
-  HIPCHK(h, hipEventRecord(r.a, st));
+  if (h->profiling) {
+    r.flops = a.flops;
+    if (h->profile_by_layer) {
+      char kn[64];
+      conv_kernel_name(a, kn, sizeof(kn));
+      snprintf(r.name, sizeof(r.name), "%s %s k%d", h->cur_tag, kn + 16, a.ksplit);
+    } else {
+      conv_kernel_name(a, r.name, sizeof(r.name));
+    }
+    HIPCHK(h, hipEventCreate(&r.a));
+    HIPCHK(h, hipEventCreate(&r.b));
+    HIPCHK(h, hipEventRecord(r.a, st));
+  }
   HIPCHK(h, launch_conv(a, st));
-  HIPCHK(h, hipEventRecord(r.b, st));
-  h->prof.push_back(r);
+  if (h->profiling && !h->profile_by_layer) {   // symbol-level stats: the conv kernel alone
+    HIPCHK(h, hipEventRecord(r.b, st));
+    h->prof.push_back(r);
+  }
+  if (a.ksplit > 1)
+    HIPCHK(h, launch_splitk_reduce(a.part, a.ksplit, a.slab, n_out, a.Cout, a.epi, a.bias, a.aux0,
+                                   a.out, st));
+  if (h->profiling && h->profile_by_layer) {    // layer-level stats: conv + its reduce
+    HIPCHK(h, hipEventRecord(r.b, st));
+    h->prof.push_back(r);
+  }
   return SGA_OK;
 }
 
@@ -463,8 +505,11 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
   // ---- hyper branch: p(z_tilde), (mu, sigma) = h_s(z_tilde) -----------------------------
   HIPCHK(h, launch_factorized(h->zt.p, h->eb_packed, h->ctx, B, g.zh * g.zw, C, il, h->sums,
                               with_grad ? h->g_zt_eb.p : nullptr, nullptr, nullptr, st));
+  h->cur_tag = "hs0.fwd";
   SGACHK(deconv_fwd(h, h->hs_f[0], h->hs_bias[0], h->zt.p, B, g.zh, g.zw, h->hs0.p, EPI_BIAS_RELU, st));
+  h->cur_tag = "hs1.fwd";
   SGACHK(deconv_fwd(h, h->hs_f[1], h->hs_bias[1], h->hs0.p, B, 2 * g.zh, 2 * g.zw, h->hs1.p, EPI_BIAS_RELU, st));
+  h->cur_tag = "hs2.fwd";
   SGACHK(conv3(h, h->hs_f[2], h->hs_bias[2], h->hs1.p, h->C15, B, g.hsh, g.hsw, h->ms.p, true, EPI_BIAS, nullptr, st));
   // ---- p(y_tilde | z_tilde) ------------------------------------------------------------------
   HIPCHK(h, launch_gaussian(h->yt.p, h->ms.p, h->ctx, B, g.yh, g.yw, g.hsh, g.hsw, C, il, h->sums,
@@ -472,32 +517,46 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
   // ---- x_tilde = g_s(y_tilde) ------------------------------------------------------------------
   const float* cur = h->yt.p;
   int hh = g.yh, ww = g.yw;
+  static const char* kFwd[3] = {"gs0.fwd", "gs1.fwd", "gs2.fwd"};
+  static const char* kIgdn[3] = {"igdn0.fwd", "igdn1.fwd", "igdn2.fwd"};
+  static const char* kIgdnB[3] = {"igdn0.bwd", "igdn1.bwd", "igdn2.bwd"};
+  static const char* kBwd[3] = {"gs0.bwd", "gs1.bwd", "gs2.bwd"};
   for (int L = 0; L < 3; ++L) {
+    h->cur_tag = kFwd[L];
     SGACHK(deconv_fwd(h, h->gs_f[L], h->gs_bias[L], cur, B, hh, ww, h->u[L].p, EPI_BIAS, st));
     hh *= 2; ww *= 2;
+    h->cur_tag = kIgdn[L];
     SGACHK(gdn_fwd(h, h->gs_gdn_f[L], h->gs_beta[L], h->u[L].p, B, hh, ww, h->s[L].p, h->v[L].p, true, st));
     cur = h->v[L].p;
   }
+  h->cur_tag = "gs3.fwd";
   SGACHK(deconv_to3(h, h->gs_f[3], h->gs_bias[3], cur, B, hh, ww, g.H, g.W, h->xt.p, st));
   HIPCHK(h, launch_mse(x, h->xt.p, with_grad ? h->ctx : nullptr, B, g.H, g.W, g.Hp, g.Wp, h->sums,
                        with_grad ? h->gpad.p : nullptr, nullptr, st));
   if (!with_grad) return SGA_OK;
   // ---- data-gradients: synthesis --------------------------------------------------------------
   // hh,ww = 8yh,8yw: gradient w.r.t. v[2] from the bordered gradient image
+  h->cur_tag = "gs3.bwd";
   SGACHK(conv_smallc(h, h->gs_b[3], nullptr, h->gpad.p, B, g.Hp, g.Wp, hh, ww, h->gA.p, st));
   for (int L = 2; L >= 0; --L) {
+    h->cur_tag = kIgdnB[L];
     SGACHK(igdn_bwd(h, h->gs_gdn_b[L], h->gA.p, h->u[L].p, h->s[L].p, B, hh, ww, h->gB.p, st));
     float* dst = (L == 0) ? h->g_yt_dist.p : h->gA.p;
+    h->cur_tag = kBwd[L];
     SGACHK(conv5s2(h, h->gs_b[L], nullptr, h->gB.p, B, hh, ww, hh / 2, ww / 2, dst, EPI_BIAS, nullptr, st));
     hh /= 2; ww /= 2;
   }
   // ---- data-gradients: hyper-synthesis ----------------------------------------------------------
+  h->cur_tag = "hs2.bwd";
   SGACHK(conv3(h, h->hs_b[2], nullptr, h->g_ms.p, 2 * C, B, g.hsh, g.hsw, h->g_hs1.p, false,
                EPI_RELU_MASK, h->hs1.p, st));
+  h->cur_tag = "hs1.bwd";
   SGACHK(conv5s2(h, h->hs_b[1], nullptr, h->g_hs1.p, B, g.hsh, g.hsw, 2 * g.zh, 2 * g.zw, h->g_hs0.p,
                  EPI_RELU_MASK, h->hs0.p, st));
+  h->cur_tag = "hs0.bwd";
   SGACHK(conv5s2(h, h->hs_b[0], nullptr, h->g_hs0.p, B, 2 * g.zh, 2 * g.zw, g.zh, g.zw, h->g_zt_hs.p,
                  EPI_BIAS, nullptr, st));
+  h->cur_tag = "";
   return SGA_OK;
 }
 
@@ -642,6 +701,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   }
   TRY(alloc_buf(h, h->gA, h->u[2].cap)); TRY(alloc_buf(h, h->gB, h->u[2].cap));
   TRY(alloc_buf(h, h->scratch, 8 + B * 8));
+  TRY(alloc_buf(h, h->part, (size_t)16 << 20));      // 64 MiB
   TRY(alloc_buf(h, h->trace, (size_t)kMaxIts * 4));
   TRY(alloc_buf(h, h->Ttab, kMaxIts)); TRY(alloc_buf(h, h->lrtab, kMaxIts));
   {
@@ -656,6 +716,10 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   if (hipDeviceSynchronize() != hipSuccess) return fail(SGA_ERR_HIP);
   const char* env = getenv("SGA_NO_GRAPH");
   h->use_graph = !(env && env[0] == '1');
+  env = getenv("SGA_NO_SPLITK");
+  h->no_splitk = env && env[0] == '1';
+  env = getenv("SGA_PROFILE_BY_LAYER");
+  h->profile_by_layer = env && env[0] == '1';
 #undef TRY
   *out = h;
   return SGA_OK;
@@ -718,11 +782,10 @@ int sga_step_grads(sga_handle* h, const float* x, int B, int H, int W, const flo
 }
 
 int sga_adam(sga_handle* h, float* p, const float* g, float* m, float* v, int64_t n, int t,
-             float lr, float beta1, float beta2, float eps, void* stream) {
+             double lr, double beta1, double beta2, double eps, void* stream) {
   if (!h || !p || !g || !m || !v || n <= 0 || t <= 0) return SGA_ERR_BAD_ARG;
   // adam.py:40-42 in double, cast to float32 at the multiply
-  const double lr_t = (double)lr * (std::sqrt(1.0 - std::pow((double)beta2, t)) /
-                                    (1.0 - std::pow((double)beta1, t)));
+  const double lr_t = lr * (std::sqrt(1.0 - std::pow(beta2, t)) / (1.0 - std::pow(beta1, t)));
   HIPCHK(h, launch_adam(p, g, m, v, n, (float)lr_t, beta1, beta2, eps, (hipStream_t)stream));
   return SGA_OK;
 }
@@ -738,7 +801,7 @@ int sga_eval(sga_handle* h, const float* x, int B, int H, int W, const float* y_
 }
 
 int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, float loss_scale,
-            int its, float lr, float annealing_rate, int t0, float T_ub, uint64_t seed,
+            int its, double lr, double annealing_rate, int t0, double T_ub, uint64_t seed,
             const float* y0, const float* z0, float* y_hat, float* z_hat, float* metrics,
             float* trace, void* stream) {
   if (!h || !x || its < 0 || its > kMaxIts || (y0 == nullptr) != (z0 == nullptr)) return SGA_ERR_BAD_ARG;
@@ -767,11 +830,11 @@ int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, fl
     // host tables: utils.py:166-180 ('exp0') and adam.py:40-42, evaluated in double
     h->hT.resize(its); h->hLr.resize(its);
     for (int it = 0; it < its; ++it) {
-      double tau = (double)T_ub * std::exp(-(double)annealing_rate * (double)(it - t0));
-      tau = std::fmin(std::fmax(tau, 1e-8), (double)T_ub);
+      double tau = T_ub * std::exp(-annealing_rate * (double)(it - t0));
+      tau = std::fmin(std::fmax(tau, 1e-8), T_ub);
       h->hT[it] = (float)tau;
       const int t = it + 1;
-      h->hLr[it] = (float)((double)lr * (std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t))));
+      h->hLr[it] = (float)(lr * (std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t))));
     }
     // previous run's tables may still be in use on this stream only; same-stream order suffices
     HIPCHK(h, hipMemcpyAsync(h->Ttab.p, h->hT.data(), its * sizeof(float), hipMemcpyHostToDevice, st));

@@ -76,12 +76,23 @@ struct ConvArgs {
   int smallc;              // 1: `in` is a zero-padded 3-channel image [B,Hin,Win,3], 5x5/2 conv
   int pro, epi;
   double flops;            // algorithmic flops of this launch (profiling only)
+  const char* tag;         // call-site label, e.g. "gs2.fwd" (profiling only)
+  // split-K: grid = tiles x ksplit; split s multiplies K-steps [s*n/S, (s+1)*n/S) of its phase and
+  // writes the raw accumulators to part + s*slab (output geometry); a fixed-order reduce kernel
+  // then sums the slabs and applies the epilogue (deterministic, no atomics).
+  int ksplit;
+  long long slab;
+  float* part;
   ConvPhase ph[4];
   ConvTap taps[28];
 };
 
 // returns hipError_t
 int launch_conv(const ConvArgs& a, hipStream_t stream);
+// out[i] = epi(sum_s part[s*slab + i]) over n floats, channel = i % cout (n, cout multiples of 4)
+int launch_splitk_reduce(const float* part, int ksplit, long long slab, long long n, int cout,
+                         int epi, const float* bias, const float* aux0, float* out,
+                         hipStream_t stream);
 // tile sizes chosen for an output width (host-side, also used to size Npad when packing)
 int conv_pick_bn(int cout, int epi);
 // kernel symbol (as rocprofv3 prints it) that launch_conv will use for these args

@@ -1,0 +1,217 @@
+"""Host driver: the counterpart of the reference's `sga.py:compress` (sga.py:37-295) on top of
+`SGACodec`.  Same inputs (.npy [N,H,W,3] uint8 or one image file), same batching rule
+(configs.py:5-9), same hyper-parameters and flags (tf_boilerplate.py:155-176), same result file
+(`rd-sga-lmbda=<l>+<runname>-input=<file>.npz` with the fields of sga.py:183).
+
+Multi-GPU: one process per GPU; the images of each reference batch are dealt
+round-robin to the ranks, every rank runs its shard with loss_scale = 1/len(reference batch) so
+per-image gradients equal the un-sharded ones, and the only collective is the final gather of
+the [N_local, 7] metrics (torch.distributed: RCCL on GPUs, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import sys
+
+import numpy as np
+
+EVAL_FIELDS = ["mse", "psnr", "msssim", "msssim_db", "est_bpp", "est_y_bpp", "est_z_bpp"]  # sga.py:183
+
+# configs.py:5
+eval_batch_num_pixels = 1e7
+
+
+def get_eval_batch_size(num_pixels_per_image):
+    """configs.py:8-9."""
+    return round(eval_batch_num_pixels / num_pixels_per_image)
+
+
+def annealed_temperature(t, r, ub, lb=1e-8, scheme="exp0", t0=700):
+    """utils.py:151-180 (numpy backend semantics, float64)."""
+    if scheme == "exp":
+        tau = math.exp(-r * t)
+    elif scheme == "exp0":
+        tau = ub * math.exp(-r * (t - t0))
+    elif scheme == "linear":
+        tau = -r * (t - t0) + ub
+    else:
+        raise NotImplementedError
+    return min(max(tau, lb), ub)
+
+
+def load_images(input_file: str) -> np.ndarray:
+    """sga.py:41-53: .npy of N same-shape images [N,H,W,3], or one image file -> float32 in [0,1]."""
+    if input_file.endswith(".npy"):
+        X = np.load(input_file)
+    else:
+        from PIL import Image
+        X = np.asarray(Image.open(input_file).convert("RGB"))[None, ...]
+    if X.ndim != 4 or X.shape[-1] != 3:
+        raise ValueError(f"expected [N,H,W,3] images, got {X.shape}")
+    X = X.astype("float32")
+    X /= 255.0
+    return X
+
+
+def lambda_from_runname(runname: str) -> float:
+    """sga.py:157-158: re-use the lmbda the model was trained with."""
+    return float(runname.split("lmbda=")[1].split("-")[0])
+
+
+def result_filename(prefix, script_name, lmbda, runname, input_file):
+    """sga.py:258-268."""
+    input_file = os.path.basename(input_file)
+    trained_script_name = runname.split("-")[0]
+    if script_name != trained_script_name:
+        return "%s-%s-lmbda=%g+%s-input=%s.npz" % (prefix, script_name, lmbda, runname, input_file)
+    return "%s-%s-input=%s.npz" % (prefix, runname, input_file)
+
+
+def reference_batches(num_images: int, batch_size: int):
+    """tf.data `.batch(batch_size)` (sga.py:56-57): consecutive chunks, last one ragged."""
+    return [list(range(s, min(s + batch_size, num_images))) for s in range(0, num_images, batch_size)]
+
+
+def shard_batch(indices, rank: int, world: int):
+    """Round-robin deal of one reference batch to the ranks."""
+    return indices[rank::world]
+
+
+def gather_metrics(local_idx, local_met, num_images, dist=None, device=None):
+    """All-gather [n_local, 7] metrics + their image indices; returns [num_images, 7] on every
+    rank.  dist=None: single process."""
+    import torch
+    out = np.full((num_images, len(EVAL_FIELDS)), np.nan, np.float32)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        if len(local_idx):
+            out[np.asarray(local_idx)] = local_met
+        return out
+    world = dist.get_world_size()
+    cap = -(-num_images // world) + 1            # same padded size on every rank
+    buf = torch.full((cap, len(EVAL_FIELDS) + 1), -1.0, dtype=torch.float32)
+    n = len(local_idx)
+    if n:
+        buf[:n, 0] = torch.as_tensor(np.asarray(local_idx, np.float32))
+        buf[:n, 1:] = torch.as_tensor(np.asarray(local_met, np.float32))
+    if device is not None:
+        buf = buf.to(device)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    for p in parts:
+        p = p.cpu().numpy()
+        keep = p[:, 0] >= 0
+        out[p[keep, 0].astype(np.int64)] = p[keep, 1:]
+    return out
+
+
+def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=700, T_ub=0.5,
+                seed=0, rank=0, world=1, dist=None, verbose=False, log_itv=100, log=print):
+    """The per-batch loop of sga.py:201-253 over a dataset X [N,H,W,3] float32.
+    Returns dict field -> [N] array (on every rank)."""
+    N, H, W, _ = X.shape
+    bs = get_eval_batch_size(H * W)
+    local_idx, local_met = [], []
+    for b_i, batch in enumerate(reference_batches(N, bs)):
+        mine = shard_batch(batch, rank, world)
+        loss_scale = 1.0 / len(batch)                   # the batch means of sga.py:147,150
+        for s in range(0, len(mine), codec.max_batch):  # workspace-sized chunks of the shard
+            idx = mine[s:s + codec.max_batch]
+            y_hat, z_hat, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr,
+                                              annealing_rate=annealing_rate, t0=t0, T_ub=T_ub,
+                                              seed=seed + 1000003 * b_i + s, loss_scale=loss_scale,
+                                              trace=verbose)
+            if verbose and tr is not None:
+                tr = tr.cpu().numpy()
+                for it in range(its):
+                    if it % log_itv == 0 or it + 1 == its:      # sga.py:216,232-233
+                        T = annealed_temperature(it, annealing_rate, T_ub, scheme="exp0", t0=t0)
+                        log("it=%d, T=%.3f rd_loss=%.4f mse=%.3f bpp=%.4f psnr=%.4f" %
+                            (it, T, tr[it, 0], tr[it, 1], tr[it, 2], tr[it, 3]))
+            local_idx += idx
+            local_met.append(met.cpu().numpy())
+    local_met = np.concatenate(local_met, 0) if local_met else np.zeros((0, len(EVAL_FIELDS)), np.float32)
+    device = codec.device if (dist is not None and dist.is_initialized()
+                              and dist.get_backend() == "nccl") else None
+    allm = gather_metrics(local_idx, local_met, N, dist, device)
+    return {k: allm[:, i].copy() for i, k in enumerate(EVAL_FIELDS)}
+
+
+def parse_args(argv):
+    """The reference's flags for `compress` (tf_boilerplate.py:91-204) + build-specific ones."""
+    p = argparse.ArgumentParser(description="SGA iterative inference on MI355X (sga.py drop-in)")
+    p.add_argument("--verbose", "-V", action="store_true")
+    p.add_argument("--num_filters", type=int, default=-1)
+    p.add_argument("--checkpoint_dir", default="./checkpoints")
+    p.add_argument("--seed", type=int, default=0)
+    sub = p.add_subparsers(dest="command")
+    c = sub.add_parser("compress")
+    c.add_argument("--results_dir", default="./results")
+    c.add_argument("--lambda", type=float, default=-1, dest="lmbda")
+    c.add_argument("--sga_its", type=int, default=2000)
+    c.add_argument("--annealing_rate", type=float, default=1e-3)
+    c.add_argument("--t0", type=int, default=700)
+    c.add_argument("--synthetic_weights", action="store_true",
+                   help="use the deterministic synthetic parameters instead of a checkpoint")
+    c.add_argument("--max_batch", type=int, default=0, help="images per GPU launch (0 = reference batch)")
+    c.add_argument("runname")
+    c.add_argument("input_file")
+    c.add_argument("output_file", nargs="?")
+    args = p.parse_args(argv)
+    return args
+
+
+def compress(args, weights=None):
+    """sga.py:37-295."""
+    import torch
+    from .codec import SGACodec
+    from .weights import make_synthetic_weights
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    X = load_images(args.input_file)
+    N, H, W, _ = X.shape
+    if args.lmbda < 0:
+        args.lmbda = lambda_from_runname(args.runname)
+        if rank == 0:
+            print("Defaulting lmbda (mse coefficient) to %g as used in model training." % args.lmbda)
+    if weights is None:
+        if args.synthetic_weights:
+            weights = make_synthetic_weights(args.num_filters, seed=0)
+        else:
+            from .tf_checkpoint import load_effective_weights
+            weights = load_effective_weights(os.path.join(args.checkpoint_dir, args.runname),
+                                             args.num_filters)
+    bs = get_eval_batch_size(H * W)
+    per_rank = -(-min(bs, N) // world)
+    max_batch = args.max_batch or per_rank
+    codec = SGACodec(weights, args.num_filters, max_batch, H, W, device=f"cuda:{local_rank}")
+    res = run_dataset(codec, X, args.lmbda, its=args.sga_its, annealing_rate=args.annealing_rate,
+                      t0=args.t0, seed=args.seed, rank=rank, world=world, dist=dist,
+                      verbose=args.verbose)
+    if rank == 0:
+        if args.results_dir:
+            os.makedirs(args.results_dir, exist_ok=True)
+            f = result_filename("rd", "sga", args.lmbda, args.runname, args.input_file)
+            np.savez(os.path.join(args.results_dir, f), **res)
+        for field in EVAL_FIELDS:
+            print("Avg {}: {:0.4f}".format(field, res[field].mean()))       # sga.py:293-295
+    return res
+
+
+def main(argv=None):
+    args = parse_args(sys.argv[1:] if argv is None else argv)
+    assert args.command == "compress", "Only compression is supported."     # sga.py:303
+    if args.num_filters <= 0:
+        raise SystemExit("--num_filters is required")
+    return compress(args)
+
+
+if __name__ == "__main__":
+    main()

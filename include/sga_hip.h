@@ -98,16 +98,19 @@ int sga_step_grads(sga_handle* h, const float* x, int B, int H, int W,
                    float* gy, float* gz, float* scalars, float* psnr, void* stream);
 
 /* ---- adam.py:20-59  one update of one array, t = iterations+1 (float32 arithmetic) ------ */
+/* lr/beta/eps are double: adam.py:40-45 evaluates lr_t and (1 - beta) in double before the cast */
 int sga_adam(sga_handle* h, float* p, const float* g, float* m, float* v, int64_t n, int t,
-             float lr, float beta1, float beta2, float eps, void* stream);
+             double lr, double beta1, double beta2, double eps, void* stream);
 
 /* ---- sga.py:207-247  encode + `its` x (sample, fwd, bwd, Adam) + round + eval -----------
  * y_hat/z_hat: rounded latents (np.round, half-to-even); metrics[B][7] in the order of
  * sga.py:183 {mse, psnr, msssim, msssim_db, est_bpp, est_y_bpp, est_z_bpp};
  * trace[its][4] = {rd_loss, train_mse, train_bpp, mean psnr} per step, or NULL.
- * y0/z0: optional initial latents (NULL -> sga_encode(x)). */
+ * y0/z0: optional initial latents (NULL -> sga_encode(x)).
+ * lr / annealing_rate / T_ub are double: the schedule (utils.py:166-180) and lr_t (adam.py:40-42)
+ * are evaluated in double on the host and cast to float32 per step, as the reference does. */
 int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, float loss_scale,
-            int its, float lr, float annealing_rate, int t0, float T_ub, uint64_t seed,
+            int its, double lr, double annealing_rate, int t0, double T_ub, uint64_t seed,
             const float* y0, const float* z0,
             float* y_hat, float* z_hat, float* metrics, float* trace, void* stream);
 

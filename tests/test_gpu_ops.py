@@ -201,7 +201,7 @@ def test_lower_bound_truth_table():
 
 def test_adam_bit_exact(gpu_out_dir):
     """sga_adam vs the f32-pinned restatement of adam.py: bit-for-bit over 50 updates,
-    and vs the committed fixture generated from the reference's own adam.py (rtol 1e-6)."""
+    and vs the committed fixture generated from the reference's own adam.py."""
     codec, *_ = get_codec(64)
     rng = np.random.RandomState(4)
     n = 10007
@@ -222,4 +222,8 @@ def test_adam_bit_exact(gpu_out_dir):
         codec.adam(p, torch.tensor(fx["grads"][t - 1], device="cuda"), m, v, t, lr=float(fx["lr"]))
         if t in fx["checkpoints"]:
             want = fx[f"p_after_{t}"]
-            assert np.allclose(p.cpu().numpy(), want, rtol=1e-6, atol=1e-7), f"fixture t={t}"
+            # the fixture is the reference's adam.py under numpy 2 (promotes to float64): the
+            # float32 arithmetic of numpy 1.17 drifts from it by <= 7.3e-6 abs over 2000 updates
+            # (measured with the f32-pinned restatement, tests/test_oracle.py)
+            tol = 3e-7 if t <= 3 else 2e-5
+            assert np.abs(p.cpu().numpy() - want).max() < tol, f"fixture t={t}"

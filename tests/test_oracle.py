@@ -1,0 +1,189 @@
+"""CPU tests of the oracle (no GPU): pin it against everything the reference lets us pin
+(adam.py and configs.py fixtures generated from the reference itself, Random123's published
+Philox known-answer vectors) and check the self-consistency properties of SURVEY.md 8(c)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sga_amd
+from oracle import philox
+from oracle.sga_oracle import (AdamF32, SGAOracle, annealed_temperature, get_eval_batch_size,
+                               lower_bound)
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def orc():
+    w = sga_amd.make_synthetic_weights(64, seed=0)
+    return SGAOracle(w), SGAOracle(w, dtype=torch.float64), w
+
+
+def test_philox_known_answer_vectors():
+    """Random123 kat_vectors: philox4x32 10 rounds."""
+    r = philox.philox4x32_10(0, 0, 0, 0, 0, 0)
+    assert [int(v) for v in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = 0xffffffff
+    r = philox.philox4x32_10(f, f, f, f, f, f)
+    assert [int(v) for v in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    r = philox.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
+    assert [int(v) for v in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_uniforms_strictly_inside_unit_interval():
+    """u must never be 0 or 1 (Gumbel = -log(-log u)): all 2^23 mantissa patterns map inside."""
+    b = np.array([0, 0xFFFFFFFF, 0xFFFFFE00, 0x000001FF, 0x80000000], dtype=np.uint32)
+    u = philox.bits_to_uniform(b)
+    assert u.dtype == np.float32 and (u > 0).all() and (u < 1).all()
+    assert u[1] == np.float32(1) - np.float32(2.0 ** -24)
+    u = philox.sga_uniforms(200000, 3, 0, 12345)
+    assert u.shape == (200000, 2) and (u > 0).all() and (u < 1).all()
+    assert abs(u.mean() - 0.5) < 3e-3
+    assert not np.array_equal(u, philox.sga_uniforms(200000, 4, 0, 12345))
+    assert not np.array_equal(u, philox.sga_uniforms(200000, 3, 1, 12345))
+
+
+def test_adam_matches_reference_fixture():
+    """oracle AdamF32 vs /root/reference/adam.py outputs (tests/golden/adam_reference.npz,
+    made by scripts/make_golden_from_reference.py).  The reference ran under numpy 2 (float64
+    promotion); the f32-pinned restatement must stay within float32 drift of it."""
+    fx = np.load(os.path.join(GOLDEN, "adam_reference.npz"))
+    opt = AdamF32(lr=float(fx["lr"]))
+    p = [fx["p0"].copy()]
+    for t in range(1, int(fx["steps"]) + 1):
+        p = opt.update(p, [fx["grads"][t - 1]])
+        assert p[0].dtype == np.float32
+        if t in fx["checkpoints"]:
+            d = np.abs(p[0] - fx[f"p_after_{t}"]).max()
+            assert d < (3e-7 if t <= 3 else 2e-5), (t, d)
+
+
+def test_adam_float64_restatement_is_exact():
+    """The same recurrence evaluated in float64 reproduces the reference bit-for-bit: the
+    restatement itself (not just its precision) is pinned."""
+    fx = np.load(os.path.join(GOLDEN, "adam_reference.npz"))
+    lr, b1, b2, eps = float(fx["lr"]), 0.9, 0.999, 1e-8
+    p = fx["p0"].copy()
+    m = np.zeros_like(p); v = np.zeros_like(p)
+    for t in range(1, int(fx["steps"]) + 1):
+        g = fx["grads"][t - 1]
+        lr_t = lr * (np.sqrt(1. - np.power(b2, t)) / (1. - np.power(b1, t)))
+        m = (b1 * m) + (1. - b1) * g
+        v = (b2 * v) + (1. - b2) * np.square(g)
+        p = p - lr_t * m / (np.sqrt(v) + eps)
+        if t in fx["checkpoints"]:
+            assert np.array_equal(np.asarray(p, np.float64), fx[f"p_after_{t}"]), t
+
+
+def test_eval_batch_size_fixture():
+    with open(os.path.join(GOLDEN, "eval_batch_sizes.json")) as f:
+        fx = json.load(f)
+    for px, want in fx.items():
+        assert get_eval_batch_size(int(px)) == want
+    from sga_amd.driver import get_eval_batch_size as host_fn
+    for px, want in fx.items():
+        assert host_fn(int(px)) == want
+
+
+def test_temperature_schedule():
+    """utils.py:166-180 'exp0': T(0)=T(700)=0.5, T(1999)=0.5*exp(-1.299)."""
+    assert annealed_temperature(0) == 0.5
+    assert annealed_temperature(700) == 0.5
+    assert abs(annealed_temperature(1999) - 0.5 * np.exp(-1.299)) < 1e-12
+    assert annealed_temperature(10 ** 6) == 1e-8
+    from sga_amd.driver import annealed_temperature as host_fn
+    for t in (0, 1, 699, 700, 701, 1500, 1999):
+        assert host_fn(t, r=1e-3, ub=0.5, t0=700) == annealed_temperature(t)
+
+
+def test_lower_bound_truth_table():
+    x = torch.tensor([0.5, 0.5, 2.0, 2.0], requires_grad=True)
+    g = torch.tensor([1.0, -1.0, 1.0, -1.0])
+    y = lower_bound(x, 1.0)
+    assert y.tolist() == [1.0, 1.0, 2.0, 2.0]
+    (gx,) = torch.autograd.grad(y, x, g)
+    assert gx.tolist() == [0.0, -1.0, 1.0, -1.0]
+
+
+def test_likelihood_masses_sum_to_one(orc):
+    o32, o64, _ = orc
+    ks = torch.arange(-400, 401, dtype=torch.float64)
+    grid = ks[:, None].repeat(1, 64)
+    assert torch.allclose(o64.eb_likelihood(grid).sum(0), torch.ones(64, dtype=torch.float64), atol=1e-6)
+    for sig in (0.11, 0.5, 3.0, 40.0):
+        p = SGAOracle.gauss_likelihood(ks, torch.full_like(ks, 0.3), torch.full_like(ks, sig))
+        assert abs(float(p.sum()) - 1) < 1e-9
+    d = torch.tensor(1.37, dtype=torch.float64)
+    mu, s = torch.tensor(0.2, dtype=torch.float64), torch.tensor(0.9, dtype=torch.float64)
+    assert torch.isclose(SGAOracle.gauss_likelihood(mu + d, mu, s), SGAOracle.gauss_likelihood(mu - d, mu, s))
+
+
+def test_sampler_limits(orc):
+    rng = np.random.RandomState(0)
+    v = torch.tensor(rng.standard_normal(4000) * 3)
+    v = v[(v - v.round()).abs() < 0.3]
+    u = torch.tensor(rng.uniform(0.05, 0.95, (v.numel(), 2)))
+    vt = SGAOracle.sga_sample(v, 0.02, u)
+    assert (vt - v.round()).abs().max() < 1e-3                 # T -> 0: round to nearest
+    ints = torch.tensor([0.0, 3.0, -2.0], dtype=torch.float64, requires_grad=True)
+    out = SGAOracle.sga_sample(ints, 0.5, torch.full((3, 2), 0.3, dtype=torch.float64))
+    assert torch.equal(out.detach(), ints.detach())            # fl == ce: v_tilde = v
+    (g,) = torch.autograd.grad(out.sum(), ints)
+    assert torch.equal(g, torch.zeros(3, dtype=torch.float64))  # and zero gradient
+    # E[s_up] grows with frac(v)
+    fr = torch.linspace(0.05, 0.95, 10, dtype=torch.float64)
+    uu = torch.tensor(rng.uniform(1e-3, 1 - 1e-3, (4000, 10, 2)))
+    m = SGAOracle.sga_sample(fr[None, :].repeat(4000, 1), 0.5, uu).mean(0)
+    assert (m[1:] > m[:-1]).all()
+
+
+def test_step_f32_matches_f64(orc):
+    """The float32 oracle (the thing timed as cpu_baseline) agrees with float64 autograd."""
+    o32, o64, _ = orc
+    x = np.random.RandomState(1).rand(2, 48, 40, 3).astype(np.float32)
+    y, z = o32.encode(x)
+    u_y = philox.sga_uniforms(y.numel(), 0, 0, 1)
+    u_z = philox.sga_uniforms(z.numel(), 0, 1, 1)
+    a = o32.step(x, y, z, 0.3, u_y, u_z, 0.01)
+    b = o64.step(x, y.numpy(), z.numpy(), 0.3, u_y, u_z, 0.01)
+    for k in ("gy", "gz"):
+        e = (a[k].double() - b[k]).abs().max() / b[k].abs().max()
+        assert e < 1e-4, (k, float(e))
+    assert abs(a["rd_loss"] - b["rd_loss"]) < 1e-4 * abs(b["rd_loss"])
+
+
+def test_crops_and_shapes_ragged(orc):
+    """sizes that are not multiples of 16/64 exercise the mu/sigma and x_tilde crops."""
+    o32, _, _ = orc
+    for H, W in ((50, 70), (37, 41), (64, 64)):
+        x = np.random.RandomState(2).rand(1, H, W, 3).astype(np.float32)
+        y, z = o32.encode(x)
+        h, w = -(-H // 16), -(-W // 16)
+        assert tuple(y.shape) == (1, h, w, 64)
+        assert tuple(z.shape) == (1, -(-(-(-h // 2)) // 2), -(-(-(-w // 2)) // 2), 64)
+        ev = o32.evaluate(x, np.round(y.numpy()), np.round(z.numpy()))
+        assert np.isfinite(ev["est_bpp"]).all() and np.isfinite(ev["psnr"]).all()
+
+
+def test_run_improves_objective(orc):
+    """A short SGA run lowers the (relaxed) R-D loss and is reproducible for a fixed seed."""
+    o32, _, _ = orc
+    x = np.random.RandomState(3).rand(1, 32, 32, 3).astype(np.float32)
+    y1, z1, m1, tr1 = o32.run(x, 0.01, its=30, seed=5, trace=True)
+    y2, z2, m2, tr2 = o32.run(x, 0.01, its=30, seed=5, trace=True)
+    assert np.array_equal(y1, y2) and np.array_equal(tr1, tr2)
+    assert tr1[-5:, 0].mean() < tr1[:5, 0].mean()
+
+
+def test_synthetic_weights_digest():
+    """The generator is deterministic; its output is pinned by hash, not by committed tensors."""
+    w = sga_amd.make_synthetic_weights(64, seed=0)
+    assert sga_amd.weights_digest(w) == sga_amd.weights_digest(sga_amd.make_synthetic_weights(64, seed=0))
+    assert sga_amd.weights_digest(w) != sga_amd.weights_digest(sga_amd.make_synthetic_weights(64, seed=1))
+    with open(os.path.join(GOLDEN, "weights_digest.json")) as f:
+        fx = json.load(f)
+    assert sga_amd.weights_digest(w) == fx["C64_seed0"]
+    sga_amd.check_weights(w, 64)
