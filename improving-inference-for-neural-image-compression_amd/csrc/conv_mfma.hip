@@ -42,9 +42,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/loader mismatch");
   constexpr int PX = (PRO == PRO_IGDN_BWD) ? PA : 1;
 
+  constexpr int CPITCH = TN * 32 + 4;         // epilogue staging pitch (floats) per wave row
+  constexpr int MAIN_FLOATS = (BM + BN) * LDK;
+  constexpr int EPI_FLOATS = WM * WN * 32 * CPITCH;
+  constexpr int LDS_FLOATS = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + BM * LDK;
+  long long* rowpix = reinterpret_cast<long long*>(smem + LDS_FLOATS);   // [BM] output pixel index or -1
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
@@ -83,6 +88,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
       a_ix[p] = 0;
       a_base[p] = 0;
     }
+  }
+
+  // output pixel of every tile row (epilogue), -1 if the row is past M or outside the output
+  for (int r = tid; r < BM; r += NT) {
+    const int m = m0 + r;
+    long long px = -1;
+    if (m < Mtot) {
+      const int j = m % a.Wg;
+      const int t = m / a.Wg;
+      const int i = t % a.Hg;
+      const int b = t / a.Hg;
+      const int oy = i * a.s_out + ph.py, ox = j * a.s_out + ph.px;
+      if (oy < a.Hout && ox < a.Wout) px = ((long long)b * a.Hout + oy) * a.Wout + ox;
+    }
+    rowpix[r] = px;
   }
 
   f32x4 ra[PA], rb[PB], ra1[PX], ra2[PX];
@@ -190,72 +210,96 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)
+  // ---- epilogue -------------------------------------------------------------------------------
+  // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
   const int half = lane >> 5, col = lane & 31;
+  if (a.epi == EPI_SHUFFLE3 && a.ksplit <= 1) {
+    // columns n = (py*2+px)*3 + c of a combined-phase C->3 transposed conv (scalar scatter)
+    if (TN == 1 && wn == 0) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+          const int m = m0 + (wm * TM + tm) * 32 + row;
+          const int n = n0 + col;
+          if (m >= Mtot || n >= 12) continue;
+          const int j = m % a.Wg;
+          const int t = m / a.Wg;
+          const int i = t % a.Hg;
+          const int b = t / a.Hg;
+          const int pp = n / 3, c = n - pp * 3;
+          const int oy = 2 * i + (pp >> 1), ox = 2 * j + (pp & 1);
+          if (oy < a.Hout && ox < a.Wout)
+            a.out[((size_t)(b * a.Hout + oy) * a.Wout + ox) * 3 + c] =
+                acc[tm][0][reg] + (a.bias ? a.bias[c] : 0.f);
+        }
+      }
+    }
+    return;
+  }
+  // Stage each wave's 32 x (TN*32) accumulator slab through LDS and emit whole 16-byte pieces of
+  // output rows (coalesced float4 stores and aux loads instead of 4-byte column scatters).
   const int epi = a.ksplit > 1 ? -1 : a.epi;      // split-K: raw partial sums, epilogue in the reduce
   float* const outp = a.ksplit > 1 ? a.part + (size_t)split * a.slab : a.out;
+  float* Cs = smem + wid * (32 * CPITCH);
+  constexpr int F4_PER_ROW = TN * 8;
+  constexpr int F4_ITERS = (32 * F4_PER_ROW) / 64;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-      const int m = m0 + (wm * TM + tm) * 32 + row;
-      if (m >= Mtot) continue;
-      const int j = m % a.Wg;
-      const int t = m / a.Wg;
-      const int i = t % a.Hg;
-      const int b = t / a.Hg;
-      if (epi == EPI_SHUFFLE3) {
-        // columns n = (py*2+px)*3 + c of a combined-phase C->3 transposed conv
-        if (TN == 1 && wn == 0) {
-          const int n = n0 + col;
-          if (n < 12) {
-            const int pp = n / 3, c = n - pp * 3;
-            const int oy = 2 * i + (pp >> 1), ox = 2 * j + (pp & 1);
-            if (oy < a.Hout && ox < a.Wout)
-              a.out[((size_t)(b * a.Hout + oy) * a.Wout + ox) * 3 + c] =
-                  acc[tm][0][reg] + (a.bias ? a.bias[c] : 0.f);
-          }
-        }
-        continue;
-      }
-      const int oy = i * a.s_out + ph.py, ox = j * a.s_out + ph.px;
-      if (oy >= a.Hout || ox >= a.Wout) continue;
-      const size_t obase = ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.out_cs + a.out_coff;
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + (wn * TN + tn) * 32 + col;
-        if (n >= a.Cout) continue;
-        float v = acc[tm][tn][reg];
-        const size_t o = obase + n;
-        switch (epi) {
-          case EPI_BIAS:
-            if (a.bias) v += a.bias[n];
-            break;
-          case EPI_BIAS_RELU:
-            if (a.bias) v += a.bias[n];
-            v = fmaxf(v, 0.f);
-            break;
-          case EPI_IGDN: {
-            const float s = sqrtf(v + a.bias[n]);
-            a.aux_out[o] = s;
-            v = a.aux0[o] * s;
-          } break;
-          case EPI_GDN:
-            v = a.aux0[o] / sqrtf(v + a.bias[n]);
-            break;
-          case EPI_IGDN_BWD:
-            v = a.in[o] * a.aux1[o] + a.aux2[o] * v;
-            break;
-          case EPI_RELU_MASK:
-            v = a.aux0[o] > 0.f ? v : 0.f;
-            break;
-          default:
-            break;
-        }
-        outp[o] = v;
+      for (int reg = 0; reg < 16; ++reg)
+        Cs[((reg & 3) + 8 * (reg >> 2) + 4 * half) * CPITCH + tn * 32 + col] = acc[tm][tn][reg];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < F4_ITERS; ++k) {
+      const int f = lane + 64 * k;
+      const int row = f / F4_PER_ROW, c4 = f - row * F4_PER_ROW;
+      const long long px = rowpix[(wm * TM + tm) * 32 + row];
+      const int n = n0 + (wn * TN) * 32 + c4 * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * CPITCH + c4 * 4]);
+      if (px < 0 || n >= a.Cout) continue;
+      const size_t o = (size_t)px * a.out_cs + a.out_coff + n;
+      switch (epi) {
+        case EPI_BIAS:
+          if (a.bias) v += ld4(a.bias + n);
+          break;
+        case EPI_BIAS_RELU: {
+          if (a.bias) v += ld4(a.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } break;
+        case EPI_IGDN: {
+          const f32x4 u = ld4(a.aux0 + o);
+          const f32x4 nb = v + ld4(a.bias + n);
+          f32x4 sq;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sq[e] = sqrtf(nb[e]);
+          *reinterpret_cast<f32x4*>(a.aux_out + o) = sq;
+          v = u * sq;
+        } break;
+        case EPI_GDN: {
+          const f32x4 u = ld4(a.aux0 + o);
+          const f32x4 nb = v + ld4(a.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = u[e] / sqrtf(nb[e]);
+        } break;
+        case EPI_IGDN_BWD:
+          v = ld4(a.in + o) * ld4(a.aux1 + o) + ld4(a.aux2 + o) * v;
+          break;
+        case EPI_RELU_MASK: {
+          const f32x4 mk = ld4(a.aux0 + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+        } break;
+        default:
+          break;
       }
+      *reinterpret_cast<f32x4*>(outp + o) = v;
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -286,7 +330,16 @@ template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC>
 int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  const size_t lds = (size_t)(BM + BN) * LDK * sizeof(float);
+  constexpr int MAIN_FLOATS = (BM + BN) * LDK;
+  constexpr int EPI_FLOATS = WM * WN * 32 * (TN * 32 + 4);
+  const size_t lds = (size_t)(MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS) * sizeof(float) +
+                     BM * sizeof(long long);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
   const int grid = a.nphase * a.tiles_per_phase * a.ntiles_n * (a.ksplit > 1 ? a.ksplit : 1);
   if (grid <= 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC>), dim3(grid), dim3(NT), lds,
