@@ -83,7 +83,12 @@ struct sga_handle {
   Buf gA, gB, g_yt_dist, g_yt_rate;
   Buf scratch;                   // scalars[4] + psnr[max_batch] + metrics[max_batch*7]
   Buf trace, Ttab, lrtab;
-  Buf part;                      // split-K partial slabs
+  Buf part, partB;               // split-K partial slabs (one per concurrently running branch)
+  Buf* cur_part = nullptr;
+  // hyper-prior branch runs on its own stream, forked/joined with events (also inside the graph)
+  hipStream_t sB = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = true;             // SGA_NO_OVERLAP=1 disables
   ImgSums* sums = nullptr;
   StepCtx* ctx = nullptr;
   std::vector<float> hT, hLr;    // host tables (kept alive across the async upload)
@@ -141,7 +146,7 @@ int pick_ksplit(const sga_handle* h, const ConvArgs& a) {
   int S = 512 / blocks;
   if (S > min_steps / 2) S = min_steps / 2;      // at least 2 K-steps per split
   const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
-  const long long cap = (long long)h->part.cap / n_out;
+  const long long cap = (long long)h->cur_part->cap / n_out;
   if (S > cap) S = (int)cap;
   return S < 2 ? 1 : S;
 }
@@ -150,7 +155,7 @@ int pick_ksplit(const sga_handle* h, const ConvArgs& a) {
 int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st) {
   a.ksplit = pick_ksplit(h, a);
   const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
-  if (a.ksplit > 1) { a.part = h->part.p; a.slab = n_out; }
+  if (a.ksplit > 1) { a.part = h->cur_part->p; a.slab = n_out; }
   sga_handle::ProfRec r;
   if (h->profiling) {
     r.flops = a.flops;
@@ -496,13 +501,12 @@ int encode_impl(sga_handle* h, const Geom& g, const float* x, float* y, float* z
   return SGA_OK;
 }
 
-// forward of the rate-distortion graph given (relaxed or rounded) latents in h->yt / h->zt
-// (sga.py:100-108, 122-136, 143-150).  with_grad: also every data-gradient (sga.py:164).
-int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_grad,
-                        hipStream_t st) {
+// Hyper-prior branch given z_tilde (and y_tilde for the conditional): p(z_tilde), (mu, sigma) =
+// h_s(z_tilde), p(y_tilde | z_tilde) and, with_grad, the data-gradients back to z_tilde
+// (sga.py:100-108, 126-136 and their part of sga.py:164).  Every launch goes to `st`.
+int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st) {
   const int B = g.B, C = h->C;
   const float il = inv_ln2_hw(g);
-  // ---- hyper branch: p(z_tilde), (mu, sigma) = h_s(z_tilde) -----------------------------
   HIPCHK(h, launch_factorized(h->zt.p, h->eb_packed, h->ctx, B, g.zh * g.zw, C, il, h->sums,
                               with_grad ? h->g_zt_eb.p : nullptr, nullptr, nullptr, st));
   h->cur_tag = "hs0.fwd";
@@ -511,10 +515,26 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
   SGACHK(deconv_fwd(h, h->hs_f[1], h->hs_bias[1], h->hs0.p, B, 2 * g.zh, 2 * g.zw, h->hs1.p, EPI_BIAS_RELU, st));
   h->cur_tag = "hs2.fwd";
   SGACHK(conv3(h, h->hs_f[2], h->hs_bias[2], h->hs1.p, h->C15, B, g.hsh, g.hsw, h->ms.p, true, EPI_BIAS, nullptr, st));
-  // ---- p(y_tilde | z_tilde) ------------------------------------------------------------------
   HIPCHK(h, launch_gaussian(h->yt.p, h->ms.p, h->ctx, B, g.yh, g.yw, g.hsh, g.hsw, C, il, h->sums,
                             with_grad ? h->g_yt_rate.p : nullptr, with_grad ? h->g_ms.p : nullptr, st));
-  // ---- x_tilde = g_s(y_tilde) ------------------------------------------------------------------
+  if (!with_grad) return SGA_OK;
+  h->cur_tag = "hs2.bwd";
+  SGACHK(conv3(h, h->hs_b[2], nullptr, h->g_ms.p, 2 * C, B, g.hsh, g.hsw, h->g_hs1.p, false,
+               EPI_RELU_MASK, h->hs1.p, st));
+  h->cur_tag = "hs1.bwd";
+  SGACHK(conv5s2(h, h->hs_b[1], nullptr, h->g_hs1.p, B, g.hsh, g.hsw, 2 * g.zh, 2 * g.zw, h->g_hs0.p,
+                 EPI_RELU_MASK, h->hs0.p, st));
+  h->cur_tag = "hs0.bwd";
+  SGACHK(conv5s2(h, h->hs_b[0], nullptr, h->g_hs0.p, B, 2 * g.zh, 2 * g.zw, g.zh, g.zw, h->g_zt_hs.p,
+                 EPI_BIAS, nullptr, st));
+  h->cur_tag = "";
+  return SGA_OK;
+}
+
+// Synthesis branch given y_tilde: x_tilde = g_s(y_tilde), distortion and, with_grad, the
+// data-gradients back to y_tilde (sga.py:122-123, 150-154 and their part of sga.py:164).
+int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, hipStream_t st) {
+  const int B = g.B;
   const float* cur = h->yt.p;
   int hh = g.yh, ww = g.yw;
   static const char* kFwd[3] = {"gs0.fwd", "gs1.fwd", "gs2.fwd"};
@@ -534,7 +554,6 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
   HIPCHK(h, launch_mse(x, h->xt.p, with_grad ? h->ctx : nullptr, B, g.H, g.W, g.Hp, g.Wp, h->sums,
                        with_grad ? h->gpad.p : nullptr, nullptr, st));
   if (!with_grad) return SGA_OK;
-  // ---- data-gradients: synthesis --------------------------------------------------------------
   // hh,ww = 8yh,8yw: gradient w.r.t. v[2] from the bordered gradient image
   h->cur_tag = "gs3.bwd";
   SGACHK(conv_smallc(h, h->gs_b[3], nullptr, h->gpad.p, B, g.Hp, g.Wp, hh, ww, h->gA.p, st));
@@ -546,17 +565,34 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
     SGACHK(conv5s2(h, h->gs_b[L], nullptr, h->gB.p, B, hh, ww, hh / 2, ww / 2, dst, EPI_BIAS, nullptr, st));
     hh /= 2; ww /= 2;
   }
-  // ---- data-gradients: hyper-synthesis ----------------------------------------------------------
-  h->cur_tag = "hs2.bwd";
-  SGACHK(conv3(h, h->hs_b[2], nullptr, h->g_ms.p, 2 * C, B, g.hsh, g.hsw, h->g_hs1.p, false,
-               EPI_RELU_MASK, h->hs1.p, st));
-  h->cur_tag = "hs1.bwd";
-  SGACHK(conv5s2(h, h->hs_b[1], nullptr, h->g_hs1.p, B, g.hsh, g.hsw, 2 * g.zh, 2 * g.zw, h->g_hs0.p,
-                 EPI_RELU_MASK, h->hs0.p, st));
-  h->cur_tag = "hs0.bwd";
-  SGACHK(conv5s2(h, h->hs_b[0], nullptr, h->g_hs0.p, B, 2 * g.zh, 2 * g.zw, g.zh, g.zw, h->g_zt_hs.p,
-                 EPI_BIAS, nullptr, st));
   h->cur_tag = "";
+  return SGA_OK;
+}
+
+// forward (+ backward) of the rate-distortion graph given (relaxed or rounded) latents in
+// h->yt / h->zt.  The two branches are independent once y_tilde and z_tilde exist: the hyper
+// branch is forked to the handle's second stream and joined back before returning (the same
+// fork/join is recorded into the hipGraph when `st` is being captured).
+int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_grad,
+                        hipStream_t st) {
+  const bool fork = h->overlap && !h->profiling;
+  if (!fork) {
+    h->cur_part = &h->part;
+    SGACHK(hyper_branch(h, g, with_grad, st));
+    return synth_branch(h, g, x, with_grad, st);
+  }
+  HIPCHK(h, hipEventRecord(h->ev_fork, st));
+  HIPCHK(h, hipStreamWaitEvent(h->sB, h->ev_fork, 0));
+  h->cur_part = &h->partB;
+  int rc = hyper_branch(h, g, with_grad, h->sB);
+  h->cur_part = &h->part;
+  if (rc == SGA_OK) rc = synth_branch(h, g, x, with_grad, st);
+  // always join, even on error, so a capture in progress is not left forked
+  const hipError_t e1 = hipEventRecord(h->ev_join, h->sB);
+  const hipError_t e2 = hipStreamWaitEvent(st, h->ev_join, 0);
+  SGACHK(rc);
+  HIPCHK(h, e1);
+  HIPCHK(h, e2);
   return SGA_OK;
 }
 
@@ -586,6 +622,9 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
 void free_all(sga_handle* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->sB) (void)hipStreamDestroy(h->sB);
   for (void* p : h->owned) (void)hipFree(p);
   h->owned.clear();
 }
@@ -702,6 +741,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   TRY(alloc_buf(h, h->gA, h->u[2].cap)); TRY(alloc_buf(h, h->gB, h->u[2].cap));
   TRY(alloc_buf(h, h->scratch, 8 + B * 8));
   TRY(alloc_buf(h, h->part, (size_t)16 << 20));      // 64 MiB
+  TRY(alloc_buf(h, h->partB, (size_t)8 << 20));      // 32 MiB
+  h->cur_part = &h->part;
   TRY(alloc_buf(h, h->trace, (size_t)kMaxIts * 4));
   TRY(alloc_buf(h, h->Ttab, kMaxIts)); TRY(alloc_buf(h, h->lrtab, kMaxIts));
   {
@@ -716,6 +757,16 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   if (hipDeviceSynchronize() != hipSuccess) return fail(SGA_ERR_HIP);
   const char* env = getenv("SGA_NO_GRAPH");
   h->use_graph = !(env && env[0] == '1');
+  env = getenv("SGA_NO_OVERLAP");
+  h->overlap = !(env && env[0] == '1');
+  {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&h->sB, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+      return fail(SGA_ERR_HIP);
+  }
   env = getenv("SGA_NO_SPLITK");
   h->no_splitk = env && env[0] == '1';
   env = getenv("SGA_PROFILE_BY_LAYER");
