@@ -276,29 +276,33 @@ __global__ void k_mse(const float* __restrict__ x, const float* __restrict__ xt,
                       const StepCtx* __restrict__ ctx, int H, int W, int Hp, int Wp,
                       ImgSums* __restrict__ sums, float* __restrict__ gpad,
                       float* __restrict__ xq_out) {
+  // one thread per pixel (3 channels), grid-stride over the image; f32 partials per thread,
+  // f64 across the block, one atomic pair per block
   __shared__ double sh[32];
   const int b = blockIdx.y;
-  const int n_per_img = H * W * 3;
+  const int npix = H * W;
+  const int n_per_img = npix * 3;
   float coef = 0.f;
   if (ctx && ctx->lambda > 0.f)
     coef = ctx->lambda * 2.0f * 65025.0f * ctx->loss_scale / (float)n_per_img;
-  double acc[2] = {0.0, 0.0};
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_per_img; e += gridDim.x * blockDim.x) {
-    const size_t idx = (size_t)b * n_per_img + e;
-    const float xv = x[idx], tv = xt[idx];
-    const float d = xv - tv;
-    acc[0] += (double)(d * d);
-    const float q = rintf(fminf(fmaxf(tv, 0.f), 1.f) * 255.0f);
-    if (xq_out) xq_out[idx] = q;
-    const float dq = xv * 255.0f - q;
-    acc[1] += (double)(dq * dq);
-    if (gpad) {
-      const int c = e % 3;
-      const int pix = e / 3;
-      const int j = pix % W, i = pix / W;
-      gpad[((size_t)(b * Hp + i + 2) * Wp + j + 2) * 3 + c] = coef * (tv - xv);
+  float a0 = 0.f, a1 = 0.f;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+    const size_t idx = ((size_t)b * npix + p) * 3;
+    const int i = p / W, j = p - i * W;
+    float* gp = gpad ? gpad + ((size_t)(b * Hp + i + 2) * Wp + j + 2) * 3 : nullptr;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float xv = x[idx + c], tv = xt[idx + c];
+      const float d = xv - tv;
+      a0 += d * d;
+      const float q = rintf(fminf(fmaxf(tv, 0.f), 1.f) * 255.0f);
+      if (xq_out) xq_out[idx + c] = q;
+      const float dq = xv * 255.0f - q;
+      a1 += dq * dq;
+      if (gp) gp[c] = coef * (tv - xv);
     }
   }
+  double acc[2] = {(double)a0, (double)a1};
   block_sum<2>(acc, sh);
   if (threadIdx.x == 0) {
     atomicAdd(&sums[b].sq, acc[0]);
@@ -514,9 +518,8 @@ int launch_gaussian_op(const float* y, const float* mu, const float* sraw, int64
 
 int launch_mse(const float* x, const float* xt, const StepCtx* ctx, int B, int H, int W, int Hp,
                int Wp, ImgSums* sums, float* gpad, float* xq_out, hipStream_t s) {
-  const int n_per_img = H * W * 3;
-  hipLaunchKernelGGL(k_mse, dim3(grid_for(n_per_img, 256, 512), B), dim3(256), 0, s, x, xt, ctx, H,
-                     W, Hp, Wp, sums, gpad, xq_out);
+  hipLaunchKernelGGL(k_mse, dim3(grid_for((int64_t)H * W, 256, 64), B), dim3(256), 0, s, x, xt, ctx,
+                     H, W, Hp, Wp, sums, gpad, xq_out);
   LAUNCH_RET();
 }
 
