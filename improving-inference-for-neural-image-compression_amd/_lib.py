@@ -75,6 +75,13 @@ class SgaKernelStat(C.Structure):
                 ("flops_total", C.c_double)]
 
 
+SYMBOLS["sga_bb_init_z"] = (_I, [_P, _P, _I, _I, _I, _P, _P])
+SYMBOLS["sga_bb_step_grads"] = (_I, [_P, _P, _I, _I, _I, _P, _P, _F, _F, _F, C.c_uint64, C.c_uint32,
+                                     _P, _P, _I, _P, _P, _P, _P, _P])
+SYMBOLS["sga_bb_run"] = (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _I, _D, _D, _D, _I, _D, C.c_uint64,
+                              _P, _P, _P, _P, _P, _P])
+SYMBOLS["sga_bb_eval"] = (_I, [_P, _P, _I, _I, _I, _P, _P, _P, C.c_uint64, _P, _P])
+SYMBOLS["sga_op_factorized_density"] = (_I, [_P, _P, _I64, _P, _P, _P])
 SYMBOLS["sga_profile_begin"] = (_I, [_P])
 SYMBOLS["sga_profile_end"] = (_I, [_P, C.POINTER(SgaKernelStat), _I, C.POINTER(_I)])
 

@@ -21,6 +21,7 @@ from . import _lib
 from .weights import check_weights
 
 EVAL_FIELDS = ["mse", "psnr", "msssim", "msssim_db", "est_bpp", "est_y_bpp", "est_z_bpp"]  # sga.py:183
+BB_EVAL_FIELDS = EVAL_FIELDS + ["est_bpp_back"]                                             # bb_sga.py:181
 
 
 def _ptr(t):
@@ -196,6 +197,80 @@ class SGACodec:
         self._exit()
         return y_hat, z_hat, met
 
+    # ---- bb_sga.py (cfg 5): SGA + bits-back; needs bits_back=True ---------------------------------
+    def bb_init_z(self, y_tilde, H, W):
+        """(z_mean | z_logvar) = h_a(y_tilde) -> [B,zh,zw,2C]  (bb_sga.py:93-94,203-204,247)."""
+        yh, yw, zh, zw = self.latent_shape(H, W)
+        y_tilde = self._t(y_tilde)
+        B = y_tilde.shape[0]
+        zml = self._empty(B, zh, zw, 2 * self.C)
+        s = self._enter()
+        self._chk(self.lib.sga_bb_init_z(self.handle, _ptr(y_tilde), B, H, W, _ptr(zml), s), "sga_bb_init_z")
+        self._exit()
+        return zml
+
+    def bb_step_grads(self, x, y, zml, T, lmbda, loss_scale=None, seed=0, it=0, u_y=None, eps=None,
+                      rate_only=False):
+        """bb_sga.py:211-214 (stage 1) / :252-254 (rate_only)."""
+        x = self._t(x)
+        B, H, W, ys, zs = self._shapes(x)
+        y, zml = self._t(y, ys), self._t(zml, zs)
+        if loss_scale is None:
+            loss_scale = 1.0 / B
+        uy = self._t(u_y).reshape(*ys, 2) if u_y is not None else None
+        ep = self._t(eps).reshape(*zs[:-1], self.C) if eps is not None else None
+        gy, gz = self._empty(*ys), self._empty(*zs)
+        scal, psnr = self._empty(3), self._empty(B)
+        s = self._enter()
+        self._chk(self.lib.sga_bb_step_grads(self.handle, _ptr(x), B, H, W, _ptr(y), _ptr(zml), float(T),
+                                             float(lmbda), float(loss_scale), int(seed), int(it),
+                                             _ptr(uy), _ptr(ep), int(bool(rate_only)), _ptr(gy),
+                                             _ptr(gz), _ptr(scal), _ptr(psnr), s), "sga_bb_step_grads")
+        self._exit()
+        sc = scal.cpu().numpy()
+        return dict(gy=gy, gzml=gz, rd_loss=float(sc[0]), train_mse=float(sc[1]),
+                    train_bpp=float(sc[2]), psnr=psnr)
+
+    def bb_run(self, x, lmbda, its=2000, r_its=2000, lr=0.005, r_lr=0.003, annealing_rate=1e-3,
+               t0=700, T_ub=0.5, seed=0, loss_scale=None, trace=False):
+        """bb_sga.py:199-276 on the device. Returns (y_hat, zml, metrics[B,8], trace1, trace2)."""
+        x = self._t(x)
+        B, H, W, ys, zs = self._shapes(x)
+        if loss_scale is None:
+            loss_scale = 1.0 / B
+        y_hat, zml, met = self._empty(*ys), self._empty(*zs), self._empty(B, 8)
+        tr1 = self._empty(max(its, 1), 4) if trace else None
+        tr2 = self._empty(max(r_its, 1), 4) if trace else None
+        s = self._enter()
+        self._chk(self.lib.sga_bb_run(self.handle, _ptr(x), B, H, W, float(lmbda), float(loss_scale),
+                                      int(its), int(r_its), float(lr), float(r_lr),
+                                      float(annealing_rate), int(t0), float(T_ub), int(seed),
+                                      _ptr(y_hat), _ptr(zml), _ptr(met), _ptr(tr1), _ptr(tr2), s),
+                  "sga_bb_run")
+        self._exit()
+        return y_hat, zml, met, (tr1[:its] if trace else None), (tr2[:r_its] if trace else None)
+
+    def bb_evaluate(self, x, y_hat, zml, eps=None, seed=0):
+        x = self._t(x)
+        B, H, W, ys, zs = self._shapes(x)
+        y_hat, zml = self._t(y_hat, ys), self._t(zml, zs)
+        ep = self._t(eps).reshape(*zs[:-1], self.C) if eps is not None else None
+        met = self._empty(B, 8)
+        s = self._enter()
+        self._chk(self.lib.sga_bb_eval(self.handle, _ptr(x), B, H, W, _ptr(y_hat), _ptr(zml), _ptr(ep),
+                                       int(seed), _ptr(met), s), "sga_bb_eval")
+        self._exit()
+        return met
+
+    def factorized_density(self, v):
+        v = self._t(v)
+        p, dp = torch.empty_like(v), torch.empty_like(v)
+        s = self._enter()
+        self._chk(self.lib.sga_op_factorized_density(self.handle, _ptr(v), v.numel() // self.C,
+                                                     _ptr(p), _ptr(dp), s), "sga_op_factorized_density")
+        self._exit()
+        return p, dp
+
     # ---- measurement ---------------------------------------------------------------------------
     def profile_begin(self):
         """Time every MFMA convolution launch with hipEvents until profile_end (sga_run goes eager)."""
@@ -280,4 +355,5 @@ class SGACodec:
 def metrics_to_dict(met) -> dict:
     """[B,7] metrics tensor -> dict keyed like sga.py:183 eval_fields (numpy arrays)."""
     m = met.detach().cpu().numpy()
-    return {k: m[:, i].copy() for i, k in enumerate(EVAL_FIELDS)}
+    fields = BB_EVAL_FIELDS if m.shape[1] == 8 else EVAL_FIELDS
+    return {k: m[:, i].copy() for i, k in enumerate(fields)}

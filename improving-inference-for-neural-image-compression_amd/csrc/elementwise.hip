@@ -158,6 +158,62 @@ __device__ __forceinline__ void eb_mass(const float* __restrict__ P, float x, fl
   dp = sgnf(diff) * sg * (su * (1.0f - su) * dup_ - sl * (1.0f - sl) * dlo);
 }
 
+// Second-order forward mode through the same network: logit L, L' and L'' w.r.t. the input
+// (learned_prior.py:296-347 gives the first derivative in closed form; the gradient of the
+// density needs one more).
+__device__ __forceinline__ void eb_logit2(const float* __restrict__ P, float x, float& L,
+                                          float& L1, float& L2) {
+  float h[3], d[3], dd[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float pre = P[r] * x + P[3 + r];
+    const float pre1 = P[r];
+    const float t = tanhf(pre);
+    const float f = P[6 + r];
+    const float g1 = 1.0f + f * (1.0f - t * t);
+    const float g2 = f * (-2.0f * t * (1.0f - t * t));
+    h[r] = pre + f * t;
+    d[r] = pre1 * g1;
+    dd[r] = pre1 * pre1 * g2;
+  }
+#pragma unroll
+  for (int layer = 0; layer < 2; ++layer) {
+    const float* M = P + 9 + layer * 15;
+    float h2[3], d2[3], e2[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float pre = 0.f, pre1 = 0.f, pre2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        pre += M[r * 3 + c] * h[c];
+        pre1 += M[r * 3 + c] * d[c];
+        pre2 += M[r * 3 + c] * dd[c];
+      }
+      pre += M[9 + r];
+      const float t = tanhf(pre);
+      const float f = M[12 + r];
+      const float g1 = 1.0f + f * (1.0f - t * t);
+      const float g2 = f * (-2.0f * t * (1.0f - t * t));
+      h2[r] = pre + f * t;
+      d2[r] = pre1 * g1;
+      e2[r] = pre2 * g1 + pre1 * pre1 * g2;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { h[r] = h2[r]; d[r] = d2[r]; dd[r] = e2[r]; }
+  }
+  const float* M3 = P + 39;
+  float a = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    a += M3[c] * h[c];
+    a1 += M3[c] * d[c];
+    a2 += M3[c] * dd[c];
+  }
+  L = a + M3[3];
+  L1 = a1;
+  L2 = a2;
+}
+
 // math_ops.py:63-76: gradient of lower_bound passes if x >= bound or the gradient is negative
 __device__ __forceinline__ float lower_bound_grad(float x, float bound, float g) {
   return (x >= bound || g < 0.f) ? g : 0.f;
@@ -189,6 +245,85 @@ __global__ void k_factorized(const float* __restrict__ zt, const float* __restri
   }
   block_sum<1>(nats, sh);
   if (threadIdx.x == 0 && sums) atomicAdd(&sums[b].z_nats, nats[0]);
+}
+
+__global__ void k_factorized_pdf(const float* __restrict__ zt, const float* __restrict__ ebp,
+                                 const StepCtx* __restrict__ ctx, int n_per_img, int C,
+                                 float inv_ln2_hw, ImgSums* __restrict__ sums,
+                                 float* __restrict__ g_zt, float* __restrict__ p_out,
+                                 float* __restrict__ dp_out) {
+  __shared__ double sh[16];
+  const int b = blockIdx.y;
+  const float ls = ctx ? ctx->loss_scale : 1.0f;
+  double nats[1] = {0.0};
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_per_img; e += gridDim.x * blockDim.x) {
+    const size_t idx = (size_t)b * n_per_img + e;
+    const int c = e % C;
+    float L, L1, L2;
+    eb_logit2(ebp + (size_t)c * EB_STRIDE, zt[idx], L, L1, L2);
+    const float sg = sigmoidf(L);
+    const float sp = sg * (1.0f - sg);
+    const float p = sp * L1;                                        // density
+    const float dp = sp * (1.0f - 2.0f * sg) * L1 * L1 + sp * L2;   // its derivative
+    if (p_out) p_out[idx] = p;
+    if (dp_out) dp_out[idx] = dp;
+    const float pb = fmaxf(p, kLikBound);
+    nats[0] += (double)(-logf(pb));
+    if (g_zt) g_zt[idx] = lower_bound_grad(p, kLikBound, -ls * inv_ln2_hw / pb) * dp;
+  }
+  block_sum<1>(nats, sh);
+  if (threadIdx.x == 0 && sums) atomicAdd(&sums[b].z_nats, nats[0]);
+}
+
+// z_tilde = eps * exp(.5 logvar) + mean (bb_sga.py:99-100); ln q via utils.py:72-77
+__global__ void k_bb_sample_z(const float* __restrict__ zml, const float* __restrict__ eps_in,
+                              const StepCtx* __restrict__ ctx, int stream_id, int n_per_img, int C,
+                              float* __restrict__ zt, float* __restrict__ jac_lv,
+                              ImgSums* __restrict__ sums) {
+  __shared__ double sh[16];
+  const int b = blockIdx.y;
+  const int it = ctx->it;
+  const unsigned k0 = ctx->seed_lo, k1 = ctx->seed_hi;
+  double acc[1] = {0.0};
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_per_img; e += gridDim.x * blockDim.x) {
+    const size_t idx = (size_t)b * n_per_img + e;
+    const int c = e % C;
+    const size_t pix = idx / C;
+    const float mean = zml[pix * 2 * C + c], lv = zml[pix * 2 * C + C + c];
+    float ep;
+    if (eps_in) {
+      ep = eps_in[idx];
+    } else {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)idx, (uint32_t)((uint64_t)idx >> 32), (uint32_t)it,
+                    (uint32_t)stream_id, k0, k1, r);
+      const float u1 = bits_to_uniform(r[2]), u2 = bits_to_uniform(r[3]);
+      ep = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864769f * u2);   // Box-Muller
+    }
+    const float sd = expf(0.5f * lv);
+    const float z = ep * sd + mean;
+    zt[idx] = z;
+    if (jac_lv) jac_lv[idx] = 0.5f * ep * sd;
+    const float dz = z - mean;
+    acc[0] += (double)(-0.5f * (dz * dz * expf(-lv) + lv + 1.8378770664093453f));
+  }
+  block_sum<1>(acc, sh);
+  if (threadIdx.x == 0 && sums) atomicAdd(&sums[b].q_ln, acc[0]);
+}
+
+__global__ void k_bb_zgrad(const float* __restrict__ ga, const float* __restrict__ gb,
+                           const float* __restrict__ jac_lv, const StepCtx* __restrict__ ctx,
+                           float inv_ln2_hw, int64_t n, int C, float* __restrict__ g_zml) {
+  const float cq = -0.5f * ctx->loss_scale * inv_ln2_hw;     // d(-bpp_back)/d logvar, bb_sga.py:129-139
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t pix = i / C;
+    float g = ga[i];
+    if (gb) g += gb[i];
+    g_zml[pix * 2 * C + c] = g;
+    g_zml[pix * 2 * C + C + c] = g * jac_lv[i] + cq;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -373,6 +508,19 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
   }
 }
 
+__global__ void k_adam_ctx(float* __restrict__ p, const float* __restrict__ g,
+                           float* __restrict__ m, float* __restrict__ v, int64_t n,
+                           const StepCtx* __restrict__ ctx) {
+  const float lr_t = ctx->lr_t;
+  const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam_update(pp, g[i], mm, vv, lr_t, 0.9f, omb1, 0.999f, omb2, 1e-8f);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+
 __global__ void k_set_ctx(StepCtx* ctx, int it, int its, float T, float lr_t, float lambda,
                           float loss_scale, unsigned s_lo, unsigned s_hi) {
   ctx->it = it; ctx->its = its; ctx->T = T; ctx->lr_t = lr_t; ctx->lambda = lambda;
@@ -395,12 +543,13 @@ __global__ void k_finalize_step(ImgSums* sums, const StepCtx* __restrict__ ctx, 
   double sq = 0.0, nats = 0.0, ps = 0.0;
   for (int b = 0; b < B; ++b) {
     sq += sums[b].sq;
-    nats += sums[b].y_nats + sums[b].z_nats;
+    nats += sums[b].y_nats + sums[b].z_nats + sums[b].q_ln;     // q_ln = 0 outside bits-back
     const double mse_q = sums[b].sq_q / (npx * 3.0);
     const float pb = (float)(10.0 * log10(65025.0 / mse_q));
     if (psnr) psnr[b] = pb;
     ps += pb;
     sums[b].sq = 0.0; sums[b].sq_q = 0.0; sums[b].y_nats = 0.0; sums[b].z_nats = 0.0;
+    sums[b].q_ln = 0.0;
   }
   const float train_mse = (float)(sq * ls / (npx * 3.0) * 65025.0);
   const float train_bpp = (float)(nats * ls / (0.6931471805599453 * npx));
@@ -429,6 +578,27 @@ __global__ void k_finalize_eval(ImgSums* sums, int B, int H, int W, float* metri
   m[5] = (float)ybpp;
   m[6] = (float)zbpp;
   sums[b].sq = 0.0; sums[b].sq_q = 0.0; sums[b].y_nats = 0.0; sums[b].z_nats = 0.0;
+  sums[b].q_ln = 0.0;
+}
+
+// bb_sga.py:181-182: 8 fields, est_bpp = y_bpp + z_bpp - bpp_back
+__global__ void k_finalize_eval_bb(ImgSums* sums, int B, int H, int W, float* metrics) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double npx = (double)H * W, c = 0.6931471805599453 * npx;
+  const double mse = sums[b].sq_q / (npx * 3.0);
+  const double ybpp = sums[b].y_nats / c, zbpp = sums[b].z_nats / c, back = -sums[b].q_ln / c;
+  float* m = metrics + (size_t)b * 8;
+  m[0] = (float)mse;
+  m[1] = (float)(10.0 * log10(65025.0 / mse));
+  m[2] = __builtin_nanf("");
+  m[3] = __builtin_nanf("");
+  m[4] = (float)(ybpp + zbpp - back);
+  m[5] = (float)ybpp;
+  m[6] = (float)zbpp;
+  m[7] = (float)back;
+  sums[b].sq = 0.0; sums[b].sq_q = 0.0; sums[b].y_nats = 0.0; sums[b].z_nats = 0.0;
+  sums[b].q_ln = 0.0;
 }
 
 __global__ void k_round(const float* __restrict__ v, float* __restrict__ out, int64_t n) {
@@ -601,5 +771,43 @@ int launch_fill(float* p, float val, int64_t n, hipStream_t s) {
 
 int launch_relu_mask(const float* g, const float* act, float* out, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_relu_mask, dim3(grid_for(n)), dim3(256), 0, s, g, act, out, n);
+  LAUNCH_RET();
+}
+
+int launch_bb_sample_z(const float* zml, const float* eps_in, const StepCtx* ctx, int stream_id,
+                       int B, int npix, int C, float* zt, float* jac_lv, ImgSums* sums,
+                       hipStream_t s) {
+  const int n_per_img = npix * C;
+  hipLaunchKernelGGL(k_bb_sample_z, dim3(grid_for(n_per_img, 256, 256), B), dim3(256), 0, s, zml,
+                     eps_in, ctx, stream_id, n_per_img, C, zt, jac_lv, sums);
+  LAUNCH_RET();
+}
+
+int launch_factorized_pdf(const float* zt, const float* eb_packed, const StepCtx* ctx, int B,
+                          int npix, int C, float inv_ln2_hw, ImgSums* sums, float* g_zt,
+                          float* p_out, float* dp_out, hipStream_t s) {
+  const int n_per_img = npix * C;
+  hipLaunchKernelGGL(k_factorized_pdf, dim3(grid_for(n_per_img, 256, 256), B), dim3(256), 0, s, zt,
+                     eb_packed, ctx, n_per_img, C, inv_ln2_hw, sums, g_zt, p_out, dp_out);
+  LAUNCH_RET();
+}
+
+int launch_bb_zgrad(const float* ga, const float* gb, const float* jac_lv, const StepCtx* ctx,
+                    float inv_ln2_hw, int64_t npix_total, int C, float* g_zml, hipStream_t s) {
+  const int64_t n = npix_total * C;
+  hipLaunchKernelGGL(k_bb_zgrad, dim3(grid_for(n)), dim3(256), 0, s, ga, gb, jac_lv, ctx,
+                     inv_ln2_hw, n, C, g_zml);
+  LAUNCH_RET();
+}
+
+int launch_adam_ctx(float* p, const float* g, float* m, float* v, int64_t n, const StepCtx* ctx,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(k_adam_ctx, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, n, ctx);
+  LAUNCH_RET();
+}
+
+int launch_finalize_eval_bb(ImgSums* sums, int B, int H, int W, float* metrics8, hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize_eval_bb, dim3((B + 63) / 64), dim3(64), 0, s, sums, B, H, W,
+                     metrics8);
   LAUNCH_RET();
 }

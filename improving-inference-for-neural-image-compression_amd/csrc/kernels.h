@@ -11,6 +11,7 @@ struct ImgSums {
   double sq_q;    // sum (255x - round(255 clip(x_tilde)))^2   sga.py:170-173
   double y_nats;  // sum -ln p(y_tilde | z_tilde)              sga.py:144
   double z_nats;  // sum -ln p(z_tilde)                        sga.py:145
+  double q_ln;    // sum  ln q(z_tilde | y)  (bits-back)        bb_sga.py:102,129-130
 };
 
 // SGA relaxation sga.py:86-98 / :111-121 (+ tfp RelaxedOneHotCategorical.sample).
@@ -71,5 +72,25 @@ int launch_round_centered(const float* y, const float* ms, int B, int h, int w, 
 int launch_round_median(const float* z, const float* med, int64_t n, int C, float* out,
                         hipStream_t s);
 int launch_fill(float* p, float val, int64_t n, hipStream_t s);
+
+// ---- bits-back variant (bb_sga.py) -------------------------------------------------------------
+// z_tilde = eps*exp(.5 logvar) + mean with (mean | logvar) = zml [B,npix,2C] (bb_sga.py:99-100);
+// eps_in != null: injected normals [B,npix,C], else Philox Box-Muller (stream_id).  Writes
+// jac_lv = d z_tilde / d logvar and accumulates sum ln q(z_tilde) (utils.py:72-77).
+int launch_bb_sample_z(const float* zml, const float* eps_in, const StepCtx* ctx, int stream_id,
+                       int B, int npix, int C, float* zt, float* jac_lv, ImgSums* sums,
+                       hipStream_t s);
+// prior DENSITY p(z_tilde) = dCDF/dz (learned_prior.py:164-185) with lower bound, rate gradient
+// (needs the second derivative of the CDF network)
+int launch_factorized_pdf(const float* zt, const float* eb_packed, const StepCtx* ctx, int B,
+                          int npix, int C, float inv_ln2_hw, ImgSums* sums, float* g_zt,
+                          float* p_out, float* dp_out, hipStream_t s);
+// g_zml[..., c] = ga+gb;  g_zml[..., C+c] = (ga+gb)*jac_lv - 0.5*loss_scale*inv_ln2_hw
+int launch_bb_zgrad(const float* ga, const float* gb, const float* jac_lv, const StepCtx* ctx,
+                    float inv_ln2_hw, int64_t npix_total, int C, float* g_zml, hipStream_t s);
+// Adam with the step size taken from ctx->lr_t (plain gradient)
+int launch_adam_ctx(float* p, const float* g, float* m, float* v, int64_t n, const StepCtx* ctx,
+                    hipStream_t s);
+int launch_finalize_eval_bb(ImgSums* sums, int B, int H, int W, float* metrics8, hipStream_t s);
 // out = act > 0 ? g : 0  (ReLU backward; unit-parity op only, the step fuses it into conv epilogues)
 int launch_relu_mask(const float* g, const float* act, float* out, int64_t n, hipStream_t s);

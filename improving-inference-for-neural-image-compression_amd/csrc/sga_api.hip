@@ -81,6 +81,7 @@ struct sga_handle {
   Buf hs0, hs1, ms, g_ms, g_hs1, g_hs0, g_zt_hs, g_zt_eb;
   Buf u[3], s[3], v[3];
   Buf gA, gB, g_yt_dist, g_yt_rate;
+  Buf zml, mzml, vzml, g_zml, jac_lv, lrtab2;   // bits-back variant only
   Buf scratch;                   // scalars[4] + psnr[max_batch] + metrics[max_batch*7]
   Buf trace, Ttab, lrtab;
   Buf part, partB;               // split-K partial slabs (one per concurrently running branch)
@@ -504,11 +505,15 @@ int encode_impl(sga_handle* h, const Geom& g, const float* x, float* y, float* z
 // Hyper-prior branch given z_tilde (and y_tilde for the conditional): p(z_tilde), (mu, sigma) =
 // h_s(z_tilde), p(y_tilde | z_tilde) and, with_grad, the data-gradients back to z_tilde
 // (sga.py:100-108, 126-136 and their part of sga.py:164).  Every launch goes to `st`.
-int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st) {
+int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, bool density = false) {
   const int B = g.B, C = h->C;
   const float il = inv_ln2_hw(g);
-  HIPCHK(h, launch_factorized(h->zt.p, h->eb_packed, h->ctx, B, g.zh * g.zw, C, il, h->sums,
-                              with_grad ? h->g_zt_eb.p : nullptr, nullptr, nullptr, st));
+  if (density)   // bits-back: prior DENSITY (bb_sga.py:105-106)
+    HIPCHK(h, launch_factorized_pdf(h->zt.p, h->eb_packed, h->ctx, B, g.zh * g.zw, C, il, h->sums,
+                                    with_grad ? h->g_zt_eb.p : nullptr, nullptr, nullptr, st));
+  else
+    HIPCHK(h, launch_factorized(h->zt.p, h->eb_packed, h->ctx, B, g.zh * g.zw, C, il, h->sums,
+                                with_grad ? h->g_zt_eb.p : nullptr, nullptr, nullptr, st));
   h->cur_tag = "hs0.fwd";
   SGACHK(deconv_fwd(h, h->hs_f[0], h->hs_bias[0], h->zt.p, B, g.zh, g.zw, h->hs0.p, EPI_BIAS_RELU, st));
   h->cur_tag = "hs1.fwd";
@@ -574,17 +579,17 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
 // branch is forked to the handle's second stream and joined back before returning (the same
 // fork/join is recorded into the hipGraph when `st` is being captured).
 int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_grad,
-                        hipStream_t st) {
-  const bool fork = h->overlap && !h->profiling;
+                        hipStream_t st, bool density = false, bool do_synth = true) {
+  const bool fork = h->overlap && !h->profiling && do_synth;
   if (!fork) {
     h->cur_part = &h->part;
-    SGACHK(hyper_branch(h, g, with_grad, st));
-    return synth_branch(h, g, x, with_grad, st);
+    SGACHK(hyper_branch(h, g, with_grad, st, density));
+    return do_synth ? synth_branch(h, g, x, with_grad, st) : SGA_OK;
   }
   HIPCHK(h, hipEventRecord(h->ev_fork, st));
   HIPCHK(h, hipStreamWaitEvent(h->sB, h->ev_fork, 0));
   h->cur_part = &h->partB;
-  int rc = hyper_branch(h, g, with_grad, h->sB);
+  int rc = hyper_branch(h, g, with_grad, h->sB, density);
   h->cur_part = &h->part;
   if (rc == SGA_OK) rc = synth_branch(h, g, x, with_grad, st);
   // always join, even on error, so a capture in progress is not left forked
@@ -739,6 +744,12 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     TRY(alloc_buf(h, h->u[L], n)); TRY(alloc_buf(h, h->s[L], n)); TRY(alloc_buf(h, h->v[L], n));
   }
   TRY(alloc_buf(h, h->gA, h->u[2].cap)); TRY(alloc_buf(h, h->gB, h->u[2].cap));
+  if (cfg->bits_back) {
+    Buf* bb2[] = {&h->zml, &h->mzml, &h->vzml, &h->g_zml};
+    for (Buf* b : bb2) TRY(alloc_buf(h, *b, 2 * nz));
+    TRY(alloc_buf(h, h->jac_lv, nz));
+    TRY(alloc_buf(h, h->lrtab2, kMaxIts));
+  }
   TRY(alloc_buf(h, h->scratch, 8 + B * 8));
   TRY(alloc_buf(h, h->part, (size_t)16 << 20));      // 64 MiB
   TRY(alloc_buf(h, h->partB, (size_t)8 << 20));      // 32 MiB
@@ -1106,6 +1117,182 @@ int sga_profile_end(sga_handle* h, sga_kernel_stat* out, int max_out, int* n_out
   h->prof.clear();
   *n_out = (int)agg.size();
   for (int k = 0; k < (int)agg.size() && k < max_out && out; ++k) out[k] = agg[k];
+  return SGA_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// bits-back variant (bb_sga.py)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// (z_mean | z_logvar) = h_a(y_tilde), 2C output channels (bb_sga.py:69,93-94)
+int bb_init_z_impl(sga_handle* h, const Geom& g, const float* y_tilde, float* zml, hipStream_t st) {
+  const int B = g.B, C = h->C;
+  float* t0 = h->hs1.p; float* t1 = h->hs0.p;
+  h->cur_part = &h->part;
+  SGACHK(conv3(h, h->ha_f[0], h->ha_bias[0], y_tilde, C, B, g.yh, g.yw, t0, false, EPI_BIAS_RELU, nullptr, st));
+  SGACHK(conv5s2(h, h->ha_f[1], h->ha_bias[1], t0, B, g.yh, g.yw, g.zh1, g.zw1, t1, EPI_BIAS_RELU, nullptr, st));
+  SGACHK(conv5s2(h, h->ha_f[2], nullptr, t1, B, g.zh1, g.zw1, g.zh, g.zw, zml, EPI_BIAS, nullptr, st));
+  return SGA_OK;
+}
+
+// one evaluation of the bits-back objective and its gradients; results in the workspace:
+// g_yt_dist/g_yt_rate/dyt (stage 1) and g_zml
+int bb_step_core(sga_handle* h, const Geom& g, const float* x, const float* y, const float* zml,
+                 const float* u_y, const float* eps, bool rate_only, int eps_stream,
+                 hipStream_t st) {
+  const int C = h->C;
+  const int64_t ny = (int64_t)g.B * g.yh * g.yw * C;
+  if (rate_only) {
+    if (y != h->yt.p)
+      HIPCHK(h, hipMemcpyAsync(h->yt.p, y, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else {
+    HIPCHK(h, launch_sample(y, u_y, h->ctx, 0, h->yt.p, h->dyt.p, ny, st));
+  }
+  HIPCHK(h, launch_bb_sample_z(zml, eps, h->ctx, eps_stream, g.B, g.zh * g.zw, C, h->zt.p,
+                               h->jac_lv.p, h->sums, st));
+  SGACHK(rd_forward_backward(h, g, x, true, st, /*density=*/true, /*do_synth=*/!rate_only));
+  HIPCHK(h, launch_bb_zgrad(h->g_zt_hs.p, h->g_zt_eb.p, h->jac_lv.p, h->ctx, inv_ln2_hw(g),
+                            (int64_t)g.B * g.zh * g.zw, C, h->g_zml.p, st));
+  return SGA_OK;
+}
+
+int bb_eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, const float* zml,
+                 const float* eps, float* metrics, hipStream_t st) {
+  const int C = h->C;
+  const int64_t ny = (int64_t)g.B * g.yh * g.yw * C;
+  HIPCHK(h, hipMemsetAsync(h->sums, 0, sizeof(ImgSums) * g.B, st));
+  if (y_hat != h->yt.p)
+    HIPCHK(h, hipMemcpyAsync(h->yt.p, y_hat, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HIPCHK(h, launch_bb_sample_z(zml, eps, h->ctx, 3, g.B, g.zh * g.zw, C, h->zt.p, nullptr, h->sums, st));
+  SGACHK(rd_forward_backward(h, g, x, false, st, true, true));
+  if (metrics) HIPCHK(h, launch_finalize_eval_bb(h->sums, g.B, g.H, g.W, metrics, st));
+  return SGA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sga_bb_init_z(sga_handle* h, const float* y_tilde, int B, int H, int W, float* zml, void* stream) {
+  if (!h || !y_tilde || !zml) return SGA_ERR_BAD_ARG;
+  if (!h->cfg.bits_back) return SGA_ERR_UNSUPPORTED;
+  SGACHK(check_shape(h, B, H, W));
+  return bb_init_z_impl(h, make_geom(B, H, W), y_tilde, zml, (hipStream_t)stream);
+}
+
+int sga_bb_step_grads(sga_handle* h, const float* x, int B, int H, int W, const float* y,
+                      const float* zml, float T, float lambda, float loss_scale, uint64_t seed,
+                      uint32_t it, const float* u_y, const float* eps, int rate_only, float* gy,
+                      float* gzml, float* scalars, float* psnr, void* stream) {
+  if (!h || !y || !zml || !(T > 0.f) || (!rate_only && !x)) return SGA_ERR_BAD_ARG;
+  if (!h->cfg.bits_back) return SGA_ERR_UNSUPPORTED;
+  SGACHK(check_shape(h, B, H, W));
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(B, H, W);
+  SGACHK(ensure_borders(h, g, st));
+  HIPCHK(h, launch_set_ctx(h->ctx, (int)it, 0, T, 0.f, rate_only ? 0.f : lambda, loss_scale, seed, st));
+  HIPCHK(h, hipMemsetAsync(h->sums, 0, sizeof(ImgSums) * B, st));
+  SGACHK(bb_step_core(h, g, x, y, zml, u_y, eps, rate_only != 0, rate_only ? 2 : 1, st));
+  const int64_t ny = (int64_t)B * g.yh * g.yw * h->C, nz2 = (int64_t)B * g.zh * g.zw * h->C * 2;
+  if (gy && !rate_only)
+    HIPCHK(h, launch_combine_grad(h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, gy, ny, st));
+  if (gzml)
+    HIPCHK(h, hipMemcpyAsync(gzml, h->g_zml.p, nz2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, scalars, psnr, nullptr, st));
+  return SGA_OK;
+}
+
+int sga_bb_eval(sga_handle* h, const float* x, int B, int H, int W, const float* y_hat,
+                const float* zml, const float* eps, uint64_t seed, float* metrics, void* stream) {
+  if (!h || !x || !y_hat || !zml) return SGA_ERR_BAD_ARG;
+  if (!h->cfg.bits_back) return SGA_ERR_UNSUPPORTED;
+  SGACHK(check_shape(h, B, H, W));
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(B, H, W);
+  SGACHK(ensure_borders(h, g, st));
+  HIPCHK(h, launch_set_ctx(h->ctx, 0, 0, 1.f, 0.f, 0.f, 1.f, seed, st));
+  return bb_eval_impl(h, g, x, y_hat, zml, eps, metrics, st);
+}
+
+int sga_bb_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, float loss_scale,
+               int its, int r_its, double lr, double r_lr, double annealing_rate, int t0,
+               double T_ub, uint64_t seed, float* y_hat, float* zml_out, float* metrics,
+               float* trace1, float* trace2, void* stream) {
+  if (!h || !x || its < 0 || r_its < 0 || its > kMaxIts || r_its > kMaxIts) return SGA_ERR_BAD_ARG;
+  if (!h->cfg.bits_back) return SGA_ERR_UNSUPPORTED;
+  SGACHK(check_shape(h, B, H, W));
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(B, H, W);
+  const int C = h->C;
+  const int64_t ny = (int64_t)B * g.yh * g.yw * C, nz2 = (int64_t)B * g.zh * g.zw * C * 2;
+  SGACHK(ensure_borders(h, g, st));
+  HIPCHK(h, hipMemcpyAsync(h->xin.p, x, (size_t)B * H * W * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // bb_sga.py:202-204: y = g_a(x); (z_mean | z_logvar) = h_a(y) with the UNROUNDED y fed as y_tilde
+  SGACHK(encode_impl(h, g, h->xin.p, h->y.p, h->zml.p, st));
+  // host tables (double, cast per step)
+  const int nmax = its > r_its ? its : r_its;
+  h->hT.assign(nmax > 0 ? nmax : 1, 1.f); h->hLr.assign(nmax > 0 ? nmax : 1, 0.f);
+  std::vector<float> lr2(nmax > 0 ? nmax : 1, 0.f);
+  for (int it = 0; it < nmax; ++it) {
+    double tau = T_ub * std::exp(-annealing_rate * (double)(it - t0));
+    h->hT[it] = (float)std::fmin(std::fmax(tau, 1e-8), T_ub);
+    const int t = it + 1;
+    const double corr = std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t));
+    h->hLr[it] = (float)(lr * corr);
+    lr2[it] = (float)(r_lr * corr);
+  }
+  HIPCHK(h, hipMemcpyAsync(h->Ttab.p, h->hT.data(), h->hT.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(h->lrtab.p, h->hLr.data(), h->hLr.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(h->lrtab2.p, lr2.data(), lr2.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  // ---- stage 1: R-D optimisation of [y, z_mean, z_logvar] (bb_sga.py:205-236) ----------------
+  HIPCHK(h, hipMemsetAsync(h->my.p, 0, ny * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->vy.p, 0, ny * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->mzml.p, 0, nz2 * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->vzml.p, 0, nz2 * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->sums, 0, sizeof(ImgSums) * B, st));
+  HIPCHK(h, launch_set_ctx(h->ctx, -1, its, 0.f, 0.f, lambda, loss_scale, seed, st));
+  for (int it = 0; it < its; ++it) {
+    HIPCHK(h, launch_advance_ctx(h->ctx, h->Ttab.p, h->lrtab.p, st));
+    SGACHK(bb_step_core(h, g, h->xin.p, h->y.p, h->zml.p, nullptr, nullptr, false, 1, st));
+    HIPCHK(h, launch_adam_latent(h->y.p, h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, h->my.p, h->vy.p, ny, h->ctx, st));
+    HIPCHK(h, launch_adam_ctx(h->zml.p, h->g_zml.p, h->mzml.p, h->vzml.p, nz2, h->ctx, st));
+    HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, nullptr, nullptr, h->trace.p, st));
+  }
+  if (trace1 && its > 0)
+    HIPCHK(h, hipMemcpyAsync(trace1, h->trace.p, (size_t)its * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // ---- stage 2: fix y_tilde = round(y), rate optimisation of zml (bb_sga.py:238-261) ----------
+  HIPCHK(h, launch_round(h->y.p, h->yt.p, ny, st));          // h->yt holds y_hat from here on
+  if (y_hat) HIPCHK(h, hipMemcpyAsync(y_hat, h->yt.p, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
+  SGACHK(bb_init_z_impl(h, g, h->yt.p, h->zml.p, st));       // bb_sga.py:247
+  HIPCHK(h, hipMemsetAsync(h->mzml.p, 0, nz2 * sizeof(float), st));
+  HIPCHK(h, hipMemsetAsync(h->vzml.p, 0, nz2 * sizeof(float), st));
+  HIPCHK(h, launch_set_ctx(h->ctx, -1, r_its, 1.f, 0.f, 0.f, loss_scale, seed, st));
+  for (int it = 0; it < r_its; ++it) {
+    HIPCHK(h, launch_advance_ctx(h->ctx, h->Ttab.p, h->lrtab2.p, st));
+    SGACHK(bb_step_core(h, g, nullptr, h->yt.p, h->zml.p, nullptr, nullptr, true, 2, st));
+    HIPCHK(h, launch_adam_ctx(h->zml.p, h->g_zml.p, h->mzml.p, h->vzml.p, nz2, h->ctx, st));
+    HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, nullptr, nullptr, h->trace.p, st));
+  }
+  if (trace2 && r_its > 0)
+    HIPCHK(h, hipMemcpyAsync(trace2, h->trace.p, (size_t)r_its * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (zml_out) HIPCHK(h, hipMemcpyAsync(zml_out, h->zml.p, nz2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // ---- eval with a fresh eps draw (bb_sga.py:273-275) -------------------------------------------
+  if (metrics) {
+    HIPCHK(h, launch_set_ctx(h->ctx, 0, 0, 1.f, 0.f, 0.f, 1.f, seed, st));
+    SGACHK(bb_eval_impl(h, g, h->xin.p, h->yt.p, h->zml.p, nullptr, metrics, st));
+  }
+  return SGA_OK;
+}
+
+int sga_op_factorized_density(sga_handle* h, const float* v, int64_t n_pix, float* p, float* dp_dv,
+                              void* stream) {
+  if (!h || !v || n_pix <= 0 || n_pix * h->C > 0x7fffffffLL) return SGA_ERR_BAD_ARG;
+  HIPCHK(h, launch_factorized_pdf(v, h->eb_packed, nullptr, 1, (int)n_pix, h->C, 1.f, nullptr, nullptr,
+                                  p, dp_dv, (hipStream_t)stream));
   return SGA_OK;
 }
 

@@ -122,6 +122,32 @@ int sga_eval(sga_handle* h, const float* x, int B, int H, int W,
 int sga_base_compress(sga_handle* h, const float* x, int B, int H, int W, const float* medians,
                       float* y_hat, float* z_hat, float* metrics, void* stream);
 
+/* ---- bb_sga.py (cfg 5): SGA + bits-back; handle created with bits_back = 1 ------------------
+ * zml = concat(z_mean, z_logvar) on the channel axis, [B,zh,zw,2C] (bb_sga.py:93-95).
+ * eps: optional injected N(0,1) draws [B,zh,zw,C]; NULL -> device Philox Box-Muller. */
+/* bb_sga.py:93-94,203-204,247: (z_mean | z_logvar) = h_a(y_tilde) */
+int sga_bb_init_z(sga_handle* h, const float* y_tilde, int B, int H, int W, float* zml, void* stream);
+/* bb_sga.py:211-214 (rate_only = 0: y is relaxed, grads of rd_loss w.r.t. [y, z_mean, z_logvar])
+ * and bb_sga.py:252-254 (rate_only = 1: y is the fixed y_tilde, grads of train_bpp w.r.t. zml).
+ * scalars[3] = {rd_loss, train_mse, train_bpp}. */
+int sga_bb_step_grads(sga_handle* h, const float* x, int B, int H, int W, const float* y,
+                      const float* zml, float T, float lambda, float loss_scale, uint64_t seed,
+                      uint32_t it, const float* u_y, const float* eps, int rate_only, float* gy,
+                      float* gzml, float* scalars, float* psnr, void* stream);
+/* bb_sga.py:199-276: stage 1 (its x Adam(lr) on [y, zml]), round y, stage 2 (r_its x Adam(r_lr)
+ * on zml, rate only), eval.  metrics[B][8] = sga.py:183 fields + est_bpp_back (bb_sga.py:181).
+ * trace1[its][4] as sga_run; trace2[r_its][4] (column 2 = train_bpp).  Any output may be NULL. */
+int sga_bb_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, float loss_scale,
+               int its, int r_its, double lr, double r_lr, double annealing_rate, int t0,
+               double T_ub, uint64_t seed, float* y_hat, float* zml_out, float* metrics,
+               float* trace1, float* trace2, void* stream);
+/* bb_sga.py:273-275: eval at (y_hat, zml) with one eps draw */
+int sga_bb_eval(sga_handle* h, const float* x, int B, int H, int W, const float* y_hat,
+                const float* zml, const float* eps, uint64_t seed, float* metrics, void* stream);
+/* prior density and its derivative (learned_prior.py:164-185), v is [n_pix, C] */
+int sga_op_factorized_density(sga_handle* h, const float* v, int64_t n_pix, float* p, float* dp_dv,
+                              void* stream);
+
 /* ---- per-layer operator surface (unit parity; weights are the handle's) ------------------
  * `layer` selects the handle's layer; shapes follow nn_models.py.  in/out NHWC. */
 typedef enum sga_layer {
