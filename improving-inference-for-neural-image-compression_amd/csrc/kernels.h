@@ -94,3 +94,9 @@ int launch_adam_ctx(float* p, const float* g, float* m, float* v, int64_t n, con
 int launch_finalize_eval_bb(ImgSums* sums, int B, int H, int W, float* metrics8, hipStream_t s);
 // out = act > 0 ? g : 0  (ReLU backward; unit-parity op only, the step fuses it into conv epilogues)
 int launch_relu_mask(const float* g, const float* act, float* out, int64_t n, hipStream_t s);
+
+// ---- MS-SSIM of the final evaluation (msssim.hip) ----------------------------------------------
+int msssim_init();
+int launch_msssim(const float* xq, const float* x, int B, int H, int W, float* const* lvlA,
+                  float* const* lvlB, double* stats, int* counts_dev, float* metrics, int mstride,
+                  hipStream_t s);

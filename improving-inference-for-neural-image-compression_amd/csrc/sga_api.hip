@@ -82,6 +82,9 @@ struct sga_handle {
   Buf u[3], s[3], v[3];
   Buf gA, gB, g_yt_dist, g_yt_rate;
   Buf zml, mzml, vzml, g_zml, jac_lv, lrtab2;   // bits-back variant only
+  Buf xq;                        // reconstruction rounded to 0..255 (eval)
+  float* msA[5] = {nullptr}; float* msB[5] = {nullptr};   // MS-SSIM pyramid scratch
+  double* ms_stats = nullptr; int* ms_counts = nullptr;
   Buf scratch;                   // scalars[4] + psnr[max_batch] + metrics[max_batch*7]
   Buf trace, Ttab, lrtab;
   Buf part, partB;               // split-K partial slabs (one per concurrently running branch)
@@ -557,7 +560,7 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   h->cur_tag = "gs3.fwd";
   SGACHK(deconv_to3(h, h->gs_f[3], h->gs_bias[3], cur, B, hh, ww, g.H, g.W, h->xt.p, st));
   HIPCHK(h, launch_mse(x, h->xt.p, with_grad ? h->ctx : nullptr, B, g.H, g.W, g.Hp, g.Wp, h->sums,
-                       with_grad ? h->gpad.p : nullptr, nullptr, st));
+                       with_grad ? h->gpad.p : nullptr, with_grad ? nullptr : h->xq.p, st));
   if (!with_grad) return SGA_OK;
   // hh,ww = 8yh,8yw: gradient w.r.t. v[2] from the bordered gradient image
   h->cur_tag = "gs3.bwd";
@@ -617,7 +620,13 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
   HIPCHK(h, hipMemcpyAsync(h->zt.p, z_hat, nz * sizeof(float), hipMemcpyDeviceToDevice, st));
   HIPCHK(h, hipMemsetAsync(h->sums, 0, sizeof(ImgSums) * g.B, st));
   SGACHK(rd_forward_backward(h, g, x, false, st));
-  if (metrics) HIPCHK(h, launch_finalize_eval(h->sums, g.B, g.H, g.W, metrics, st));
+  if (metrics) {
+    HIPCHK(h, launch_finalize_eval(h->sums, g.B, g.H, g.W, metrics, st));
+    // sga.py:175-176; TF asserts H,W >= 176 for 5 scales: smaller images keep NaN
+    if (g.H >= 176 && g.W >= 176)
+      HIPCHK(h, launch_msssim(h->xq.p, x, g.B, g.H, g.W, h->msA, h->msB, h->ms_stats, h->ms_counts,
+                              metrics, 7, st));
+  }
   if (x_hat)
     HIPCHK(h, hipMemcpyAsync(x_hat, h->xt.p, (size_t)g.B * g.H * g.W * 3 * sizeof(float),
                              hipMemcpyDeviceToDevice, st));
@@ -749,6 +758,20 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     for (Buf* b : bb2) TRY(alloc_buf(h, *b, 2 * nz));
     TRY(alloc_buf(h, h->jac_lv, nz));
     TRY(alloc_buf(h, h->lrtab2, kMaxIts));
+  }
+  TRY(alloc_buf(h, h->xq, B * g.H * g.W * 3));
+  {
+    int hh = g.H, ww = g.W;
+    for (int k = 1; k < 5; ++k) {
+      hh = (hh + 1) / 2; ww = (ww + 1) / 2;
+      Buf a, b;
+      TRY(alloc_buf(h, a, B * hh * ww * 3)); TRY(alloc_buf(h, b, B * hh * ww * 3));
+      h->msA[k] = a.p; h->msB[k] = b.p;
+    }
+    void* p = nullptr;
+    TRY(dev_alloc(h, &p, sizeof(double) * 5 * B * 6)); h->ms_stats = (double*)p;
+    TRY(dev_alloc(h, &p, sizeof(int) * 8)); h->ms_counts = (int*)p;
+    if (msssim_init() != 0) return fail(SGA_ERR_HIP);
   }
   TRY(alloc_buf(h, h->scratch, 8 + B * 8));
   TRY(alloc_buf(h, h->part, (size_t)16 << 20));      // 64 MiB
@@ -1168,7 +1191,12 @@ int bb_eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_ha
     HIPCHK(h, hipMemcpyAsync(h->yt.p, y_hat, ny * sizeof(float), hipMemcpyDeviceToDevice, st));
   HIPCHK(h, launch_bb_sample_z(zml, eps, h->ctx, 3, g.B, g.zh * g.zw, C, h->zt.p, nullptr, h->sums, st));
   SGACHK(rd_forward_backward(h, g, x, false, st, true, true));
-  if (metrics) HIPCHK(h, launch_finalize_eval_bb(h->sums, g.B, g.H, g.W, metrics, st));
+  if (metrics) {
+    HIPCHK(h, launch_finalize_eval_bb(h->sums, g.B, g.H, g.W, metrics, st));
+    if (g.H >= 176 && g.W >= 176)
+      HIPCHK(h, launch_msssim(h->xq.p, x, g.B, g.H, g.W, h->msA, h->msB, h->ms_stats, h->ms_counts,
+                              metrics, 8, st));
+  }
   return SGA_OK;
 }
 

@@ -18,6 +18,7 @@ import sys
 import numpy as np
 
 EVAL_FIELDS = ["mse", "psnr", "msssim", "msssim_db", "est_bpp", "est_y_bpp", "est_z_bpp"]  # sga.py:183
+BB_EVAL_FIELDS = EVAL_FIELDS + ["est_bpp_back"]                                             # bb_sga.py:181
 
 # configs.py:5
 eval_batch_num_pixels = 1e7
@@ -79,18 +80,19 @@ def shard_batch(indices, rank: int, world: int):
     return indices[rank::world]
 
 
-def gather_metrics(local_idx, local_met, num_images, dist=None, device=None):
-    """All-gather [n_local, 7] metrics + their image indices; returns [num_images, 7] on every
+def gather_metrics(local_idx, local_met, num_images, dist=None, device=None, nfields=None):
+    """All-gather [n_local, F] metrics + their image indices; returns [num_images, F] on every
     rank.  dist=None: single process."""
     import torch
-    out = np.full((num_images, len(EVAL_FIELDS)), np.nan, np.float32)
+    nfields = nfields or len(EVAL_FIELDS)
+    out = np.full((num_images, nfields), np.nan, np.float32)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         if len(local_idx):
             out[np.asarray(local_idx)] = local_met
         return out
     world = dist.get_world_size()
     cap = -(-num_images // world) + 1            # same padded size on every rank
-    buf = torch.full((cap, len(EVAL_FIELDS) + 1), -1.0, dtype=torch.float32)
+    buf = torch.full((cap, nfields + 1), -1.0, dtype=torch.float32)
     n = len(local_idx)
     if n:
         buf[:n, 0] = torch.as_tensor(np.asarray(local_idx, np.float32))
@@ -107,9 +109,12 @@ def gather_metrics(local_idx, local_met, num_images, dist=None, device=None):
 
 
 def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=700, T_ub=0.5,
-                seed=0, rank=0, world=1, dist=None, verbose=False, log_itv=100, log=print):
-    """The per-batch loop of sga.py:201-253 over a dataset X [N,H,W,3] float32.
+                seed=0, rank=0, world=1, dist=None, verbose=False, log_itv=100, log=print,
+                method="sga", r_its=2000, r_lr=0.003):
+    """The per-batch loop of sga.py:201-253 (method "sga"), bb_sga.py:199-280 ("bb_sga") or the
+    one-shot mbt2018.py:159-180 ("mbt2018") over a dataset X [N,H,W,3] float32.
     Returns dict field -> [N] array (on every rank)."""
+    fields = BB_EVAL_FIELDS if method == "bb_sga" else EVAL_FIELDS
     N, H, W, _ = X.shape
     bs = get_eval_batch_size(H * W)
     local_idx, local_met = [], []
@@ -118,10 +123,18 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
         loss_scale = 1.0 / len(batch)                   # the batch means of sga.py:147,150
         for s in range(0, len(mine), codec.max_batch):  # workspace-sized chunks of the shard
             idx = mine[s:s + codec.max_batch]
-            y_hat, z_hat, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr,
-                                              annealing_rate=annealing_rate, t0=t0, T_ub=T_ub,
-                                              seed=seed + 1000003 * b_i + s, loss_scale=loss_scale,
-                                              trace=verbose)
+            sd = seed + 1000003 * b_i + s
+            if method == "bb_sga":
+                _, _, met, tr, _ = codec.bb_run(X[idx], lmbda, its=its, r_its=r_its, lr=lr, r_lr=r_lr,
+                                                annealing_rate=annealing_rate, t0=t0, T_ub=T_ub,
+                                                seed=sd, loss_scale=loss_scale, trace=verbose)
+            elif method == "mbt2018":
+                _, _, met = codec.base_compress(X[idx])
+                tr = None
+            else:
+                _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate,
+                                          t0=t0, T_ub=T_ub, seed=sd, loss_scale=loss_scale,
+                                          trace=verbose)
             if verbose and tr is not None:
                 tr = tr.cpu().numpy()
                 for it in range(its):
@@ -131,11 +144,11 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
                             (it, T, tr[it, 0], tr[it, 1], tr[it, 2], tr[it, 3]))
             local_idx += idx
             local_met.append(met.cpu().numpy())
-    local_met = np.concatenate(local_met, 0) if local_met else np.zeros((0, len(EVAL_FIELDS)), np.float32)
+    local_met = np.concatenate(local_met, 0) if local_met else np.zeros((0, len(fields)), np.float32)
     device = codec.device if (dist is not None and dist.is_initialized()
                               and dist.get_backend() == "nccl") else None
-    allm = gather_metrics(local_idx, local_met, N, dist, device)
-    return {k: allm[:, i].copy() for i, k in enumerate(EVAL_FIELDS)}
+    allm = gather_metrics(local_idx, local_met, N, dist, device, len(fields))
+    return {k: allm[:, i].copy() for i, k in enumerate(fields)}
 
 
 def parse_args(argv):
@@ -152,6 +165,8 @@ def parse_args(argv):
     c.add_argument("--sga_its", type=int, default=2000)
     c.add_argument("--annealing_rate", type=float, default=1e-3)
     c.add_argument("--t0", type=int, default=700)
+    c.add_argument("--method", default="sga", choices=["sga", "bb_sga", "mbt2018"],
+                   help="which reference script to mirror: sga.py, bb_sga.py or mbt2018.py compress")
     c.add_argument("--synthetic_weights", action="store_true",
                    help="use the deterministic synthetic parameters instead of a checkpoint")
     c.add_argument("--max_batch", type=int, default=0, help="images per GPU launch (0 = reference batch)")
@@ -181,26 +196,29 @@ def compress(args, weights=None):
         args.lmbda = lambda_from_runname(args.runname)
         if rank == 0:
             print("Defaulting lmbda (mse coefficient) to %g as used in model training." % args.lmbda)
+    method = getattr(args, "method", "sga")
+    bb = method == "bb_sga"
     if weights is None:
         if args.synthetic_weights:
-            weights = make_synthetic_weights(args.num_filters, seed=0)
+            weights = make_synthetic_weights(args.num_filters, seed=0, bb=bb)
         else:
             from .tf_checkpoint import load_effective_weights
             weights = load_effective_weights(os.path.join(args.checkpoint_dir, args.runname),
-                                             args.num_filters)
+                                             args.num_filters, bb=bb)
     bs = get_eval_batch_size(H * W)
     per_rank = -(-min(bs, N) // world)
     max_batch = args.max_batch or per_rank
-    codec = SGACodec(weights, args.num_filters, max_batch, H, W, device=f"cuda:{local_rank}")
+    codec = SGACodec(weights, args.num_filters, max_batch, H, W, device=f"cuda:{local_rank}",
+                     bits_back=bb)
     res = run_dataset(codec, X, args.lmbda, its=args.sga_its, annealing_rate=args.annealing_rate,
                       t0=args.t0, seed=args.seed, rank=rank, world=world, dist=dist,
-                      verbose=args.verbose)
+                      verbose=args.verbose, method=method)
     if rank == 0:
         if args.results_dir:
             os.makedirs(args.results_dir, exist_ok=True)
-            f = result_filename("rd", "sga", args.lmbda, args.runname, args.input_file)
+            f = result_filename("rd", method, args.lmbda, args.runname, args.input_file)
             np.savez(os.path.join(args.results_dir, f), **res)
-        for field in EVAL_FIELDS:
+        for field in res:
             print("Avg {}: {:0.4f}".format(field, res[field].mean()))       # sga.py:293-295
     return res
 

@@ -187,3 +187,28 @@ def test_run_deterministic(gpu_out_dir):
     c = codec.run(x, 0.01, its=25, seed=4)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert not torch.equal(a[0], c[0])
+
+
+def test_eval_msssim(gpu_out_dir):
+    """sga.py:175-176: MS-SSIM of the rounded reconstruction (TF defaults) vs the oracle."""
+    from sga_amd.codec import SGACodec, metrics_to_dict
+    C, B, H, W = 64, 2, 192, 177          # odd width: symmetric end-padding in the pyramid
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    codec = SGACodec(w, C, B, H, W)
+    orc = SGAOracle(w)
+    rng = np.random.RandomState(8)
+    # smooth-ish image so that SSIM is not degenerate
+    x = rng.rand(B, H // 8 + 1, W // 8 + 1, 3).astype(np.float32)
+    x = np.kron(x, np.ones((1, 8, 8, 1), np.float32))[:, :H, :W, :]
+    x = np.clip(x + 0.05 * rng.standard_normal(x.shape).astype(np.float32), 0, 1)
+    yo, zo = orc.encode(x)
+    y_hat, z_hat = np.round(yo.numpy()), np.round(zo.numpy())
+    want = orc.evaluate(x, y_hat, z_hat, with_msssim=True)
+    got = metrics_to_dict(codec.evaluate(x, y_hat, z_hat))
+    report(gpu_out_dir, "msssim", got=got["msssim"].tolist(), want=want["msssim"].tolist())
+    assert np.allclose(got["msssim"], want["msssim"], rtol=2e-4, atol=1e-6)
+    assert np.allclose(got["msssim_db"], want["msssim_db"], atol=2e-3)
+    # identical images: MS-SSIM = 1 up to rounding -> huge dB; small images: NaN (TF would assert)
+    small = SGACodec(w, C, 1, 64, 64)
+    m = metrics_to_dict(small.evaluate(x[:1, :64, :64], y_hat[:1, :4, :4], z_hat[:1, :1, :1]))
+    assert np.isnan(m["msssim"]).all()

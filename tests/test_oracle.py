@@ -187,3 +187,21 @@ def test_synthetic_weights_digest():
         fx = json.load(f)
     assert sga_amd.weights_digest(w) == fx["C64_seed0"]
     sga_amd.check_weights(w, 64)
+
+
+def test_msssim_oracle_properties():
+    """tf.image.ssim_multiscale restatement: identity -> 1, symmetry, monotone in noise, the
+    Gaussian window sums to 1, and TF's minimum-size rule (11 * 2^4 = 176)."""
+    from oracle.msssim import ssim_multiscale, fspecial_gauss
+    g = fspecial_gauss(dtype=torch.float64)
+    assert abs(float(g.sum()) - 1) < 1e-12 and torch.allclose(g, g.t())
+    rng = np.random.RandomState(0)
+    x = torch.tensor(rng.rand(2, 180, 200, 3) * 255)
+    assert torch.allclose(ssim_multiscale(x, x, 255.0), torch.ones(2, dtype=torch.float64))
+    y1 = (x + torch.tensor(rng.standard_normal(x.shape)) * 5).clamp(0, 255)
+    y2 = (x + torch.tensor(rng.standard_normal(x.shape)) * 25).clamp(0, 255)
+    a, b = ssim_multiscale(x, y1, 255.0), ssim_multiscale(x, y2, 255.0)
+    assert (a > b).all() and (a < 1).all() and (b > 0).all()
+    assert torch.allclose(a, ssim_multiscale(y1, x, 255.0))
+    with pytest.raises(ValueError):
+        ssim_multiscale(x[:, :100], x[:, :100], 255.0)
