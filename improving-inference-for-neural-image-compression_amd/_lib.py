@@ -82,6 +82,9 @@ SYMBOLS["sga_bb_run"] = (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _I, _D, _D, _D, _I
                               _P, _P, _P, _P, _P, _P])
 SYMBOLS["sga_bb_eval"] = (_I, [_P, _P, _I, _I, _I, _P, _P, _P, C.c_uint64, _P, _P])
 SYMBOLS["sga_op_factorized_density"] = (_I, [_P, _P, _I64, _P, _P, _P])
+SYMBOLS["sga_set_relaxation"] = (_I, [_P, _I, _I])
+RELAXATIONS = {"sga": 0, "danneal": 1, "unoise": 2, "ste": 3, "none": 4}
+SCHEDULES = {"exp0": 0, "exp": 1}
 SYMBOLS["sga_profile_begin"] = (_I, [_P])
 SYMBOLS["sga_profile_end"] = (_I, [_P, C.POINTER(SgaKernelStat), _I, C.POINTER(_I)])
 

@@ -112,6 +112,11 @@ class SGACodec:
         zc = 2 * self.C if self.bits_back else self.C
         return B, H, W, (B, yh, yw, self.C), (B, zh, zw, zc)
 
+    def set_relaxation(self, relaxation="sga", schedule="exp0"):
+        """Sibling inference methods on the same step (danneal.py / unoise.py / ste.py / map.py)."""
+        self._chk(self.lib.sga_set_relaxation(self.handle, _lib.RELAXATIONS[relaxation],
+                                              _lib.SCHEDULES[schedule]), "sga_set_relaxation")
+
     # ---- the session interactions ------------------------------------------------------------
     def encode(self, x):
         x = self._t(x)

@@ -53,7 +53,7 @@ __device__ __forceinline__ float sgnf(float t) { return (t > 0.f) - (t < 0.f); }
 // ------------------------------------------------------------------------------------------
 __global__ void k_sample(const float* __restrict__ v, const float* __restrict__ u,
                          const StepCtx* __restrict__ ctx, int stream_id, float* __restrict__ vt,
-                         float* __restrict__ dvt, int64_t n) {
+                         float* __restrict__ dvt, int64_t n, int mode) {
   const float T = ctx->T;
   const int it = ctx->it;
   const unsigned k0 = ctx->seed_lo, k1 = ctx->seed_hi;
@@ -71,6 +71,11 @@ __global__ void k_sample(const float* __restrict__ v, const float* __restrict__ 
       u1 = bits_to_uniform(r[1]);
     }
     const float x = v[idx];
+    if (mode >= 2) {   // unoise.py:76 / ste.py:78 (identity STE) / map.py: unit Jacobian
+      vt[idx] = mode == 2 ? x + (u0 - 0.5f) : (mode == 3 ? rintf(x) : x);
+      if (dvt) dvt[idx] = 1.0f;
+      continue;
+    }
     const float fl = floorf(x), ce = ceilf(x);
     const float rdn = x - fl, rup = ce - x;
     const float lo = -1.0f + kEps, hi = 1.0f - kEps;
@@ -80,7 +85,8 @@ __global__ void k_sample(const float* __restrict__ v, const float* __restrict__ 
     const float lup = -atanhf(dup) / T;
     const float g0 = -logf(-logf(u0));
     const float g1 = -logf(-logf(u1));
-    const float a0 = (ldn + g0) / T, a1 = (lup + g1) / T;
+    // danneal.py:83-84: plain softmax of the logits (no noise, no second division by T)
+    const float a0 = mode == 1 ? ldn : (ldn + g0) / T, a1 = mode == 1 ? lup : (lup + g1) / T;
     const float mx = fmaxf(a0, a1);
     const float e0 = expf(a0 - mx), e1 = expf(a1 - mx);
     const float den = e0 + e1;
@@ -90,7 +96,7 @@ __global__ void k_sample(const float* __restrict__ v, const float* __restrict__ 
       const float mdn = (rdn >= lo && rdn <= hi) ? 1.0f : 0.0f;
       const float mup = (rup >= lo && rup <= hi) ? 1.0f : 0.0f;
       // d(a1 - a0)/dv = (1/T^2) * ( mup/(1-dup^2) + mdn/(1-ddn^2) )
-      const float dd = (mup / (1.0f - dup * dup) + mdn / (1.0f - ddn * ddn)) / (T * T);
+      const float dd = (mup / (1.0f - dup * dup) + mdn / (1.0f - ddn * ddn)) / (mode == 1 ? T : T * T);
       dvt[idx] = (ce - fl) * s0 * s1 * dd;
     }
   }
@@ -656,8 +662,9 @@ inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
 #define LAUNCH_RET() return (int)hipGetLastError()
 
 int launch_sample(const float* v, const float* u, const StepCtx* ctx, int stream_id, float* vt,
-                  float* dvt, int64_t n, hipStream_t s) {
-  hipLaunchKernelGGL(k_sample, dim3(grid_for(n)), dim3(256), 0, s, v, u, ctx, stream_id, vt, dvt, n);
+                  float* dvt, int64_t n, hipStream_t s, int mode) {
+  hipLaunchKernelGGL(k_sample, dim3(grid_for(n)), dim3(256), 0, s, v, u, ctx, stream_id, vt, dvt, n,
+                     mode);
   LAUNCH_RET();
 }
 

@@ -16,8 +16,9 @@ struct ImgSums {
 
 // SGA relaxation sga.py:86-98 / :111-121 (+ tfp RelaxedOneHotCategorical.sample).
 // u != null: injected uniforms [n][2]; else Philox keyed by ctx (stream_id 0 = y, 1 = z).
+// mode: sga_relaxation (0 SGA, 1 deterministic annealing, 2 uniform noise, 3 STE, 4 none)
 int launch_sample(const float* v, const float* u, const StepCtx* ctx, int stream_id,
-                  float* vt, float* dvt, int64_t n, hipStream_t s);
+                  float* vt, float* dvt, int64_t n, hipStream_t s, int mode = 0);
 
 // Factorized prior on z_tilde [B, npix, C]: accumulates -ln p into sums[b].z_nats and writes
 // d rd_loss / d z_tilde (rate term) to g_zt.  p_out / dp_out (optional): raw mass and dp/dv.

@@ -102,7 +102,8 @@ struct sga_handle {
 
   // ---- cached step graph ----
   hipGraphExec_t graph_exec = nullptr;
-  int graph_B = 0, graph_H = 0, graph_W = 0;
+  int graph_B = 0, graph_H = 0, graph_W = 0, graph_relax = 0;
+  int relax = 0, sched = 0;        // sga_set_relaxation
   int use_graph = 1;
 
   // ---- per-kernel profiling (sga_profile_begin/end) ----
@@ -608,8 +609,8 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
 int sga_step_core(sga_handle* h, const Geom& g, const float* x, const float* y, const float* z,
                   const float* u_y, const float* u_z, hipStream_t st) {
   const int64_t ny = (int64_t)g.B * g.yh * g.yw * h->C, nz = (int64_t)g.B * g.zh * g.zw * h->C;
-  HIPCHK(h, launch_sample(z, u_z, h->ctx, 1, h->zt.p, h->dzt.p, nz, st));
-  HIPCHK(h, launch_sample(y, u_y, h->ctx, 0, h->yt.p, h->dyt.p, ny, st));
+  HIPCHK(h, launch_sample(z, u_z, h->ctx, 1, h->zt.p, h->dzt.p, nz, st, h->relax));
+  HIPCHK(h, launch_sample(y, u_y, h->ctx, 0, h->yt.p, h->dyt.p, ny, st, h->relax));
   return rd_forward_backward(h, g, x, true, st);
 }
 
@@ -915,7 +916,8 @@ int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, fl
     // host tables: utils.py:166-180 ('exp0') and adam.py:40-42, evaluated in double
     h->hT.resize(its); h->hLr.resize(its);
     for (int it = 0; it < its; ++it) {
-      double tau = T_ub * std::exp(-annealing_rate * (double)(it - t0));
+      double tau = h->sched == SGA_SCHED_EXP ? std::exp(-annealing_rate * (double)it)
+                                             : T_ub * std::exp(-annealing_rate * (double)(it - t0));
       tau = std::fmin(std::fmax(tau, 1e-8), T_ub);
       h->hT[it] = (float)tau;
       const int t = it + 1;
@@ -938,7 +940,8 @@ int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, fl
 
     bool graphed = false;
     if (h->use_graph && !h->profiling) {
-      if (!h->graph_exec || h->graph_B != B || h->graph_H != H || h->graph_W != W) {
+      if (!h->graph_exec || h->graph_B != B || h->graph_H != H || h->graph_W != W ||
+          h->graph_relax != h->relax) {
         if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -946,7 +949,7 @@ int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, fl
           const hipError_t ec = hipStreamEndCapture(st, &graph);
           if (rc == SGA_OK && ec == hipSuccess && graph &&
               hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-            h->graph_B = B; h->graph_H = H; h->graph_W = W;
+            h->graph_B = B; h->graph_H = H; h->graph_W = W; h->graph_relax = h->relax;
           } else {
             h->graph_exec = nullptr;
           }
@@ -1103,6 +1106,14 @@ int sga_op_gaussian_likelihood(sga_handle* h, const float* y, const float* mu,
                                float* dp_dmu, float* dp_dsraw, void* stream) {
   if (!h || !y || !mu || !sigma_raw || n <= 0) return SGA_ERR_BAD_ARG;
   HIPCHK(h, launch_gaussian_op(y, mu, sigma_raw, n, p, dp_dy, dp_dmu, dp_dsraw, (hipStream_t)stream));
+  return SGA_OK;
+}
+
+int sga_set_relaxation(sga_handle* h, int relaxation, int schedule) {
+  if (!h || relaxation < 0 || relaxation > SGA_RELAX_NONE || schedule < 0 || schedule > SGA_SCHED_EXP)
+    return SGA_ERR_BAD_ARG;
+  h->relax = relaxation;
+  h->sched = schedule;
   return SGA_OK;
 }
 

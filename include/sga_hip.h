@@ -122,6 +122,22 @@ int sga_eval(sga_handle* h, const float* x, int B, int H, int W,
 int sga_base_compress(sga_handle* h, const float* x, int B, int H, int W, const float* medians,
                       float* y_hat, float* z_hat, float* metrics, void* stream);
 
+/* ---- sibling relaxations on the same step ------------------------------------
+ * The ablation scripts differ from sga.py only in the op that maps (y,z) -> (y_tilde,z_tilde) and
+ * in the temperature schedule; sga_step_grads / sga_run honour the handle's current setting. */
+typedef enum sga_relaxation {
+  SGA_RELAX_SGA = 0,      /* sga.py:86-98: Gumbel-softmax over {floor, ceil}                         */
+  SGA_RELAX_DANNEAL = 1,  /* danneal.py:74-100: softmax(logits), no Gumbel noise (logits carry 1/T)  */
+  SGA_RELAX_UNOISE = 2,   /* unoise.py:76,81: v + U(-.5,.5) (first uniform of the element)           */
+  SGA_RELAX_STE = 3,      /* ste.py:78-88, utils.py:130-134: round with identity backward           */
+  SGA_RELAX_NONE = 4      /* map.py: v_tilde = v                                                     */
+} sga_relaxation;
+typedef enum sga_schedule {
+  SGA_SCHED_EXP0 = 0,     /* utils.py:170-173: T_ub*exp(-r*(t-t0)) clipped to [1e-8, T_ub]            */
+  SGA_SCHED_EXP = 1       /* danneal.py:188-193: exp(-r*t) clipped to [1e-8, T_ub]                    */
+} sga_schedule;
+int sga_set_relaxation(sga_handle* h, int relaxation, int schedule);
+
 /* ---- bb_sga.py (cfg 5): SGA + bits-back; handle created with bits_back = 1 ------------------
  * zml = concat(z_mean, z_logvar) on the channel axis, [B,zh,zw,2C] (bb_sga.py:93-95).
  * eps: optional injected N(0,1) draws [B,zh,zw,C]; NULL -> device Philox Box-Muller. */
