@@ -1,0 +1,131 @@
+// C -> 3 transposed 5x5/2 convolution (last synthesis layer, nn_models.py:60-63) as a halo-tiled
+// implicit GEMM.  In the generic gather-GEMM each of the 9 (dy,dx) taps re-reads its 128-pixel A
+// tile from global memory (876 MB per launch at B=8, 256^2: HBM-bound, PMC profile r01).  Here a
+// workgroup owns an 8 x 16 tile of input positions, stages the (8+2) x (16+2) halo of one
+// 32-channel chunk in LDS once, and all 9 taps read their A fragments from it at shifted
+// positions: 6.4x less A traffic.  N = 4 phases x 3 channels = 12 columns, padded to 16 and
+// multiplied with v_mfma_f32_16x16x4_f32 (the 32-wide MFMA would waste 62 % of the tile).
+#include "sga_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TH = 8, TW = 16;            // input positions per workgroup
+constexpr int HH = TH + 2, HW = TW + 2;   // halo
+constexpr int NPX = HH * HW;              // 180 halo pixels
+constexpr int PIT = 36;                   // LDS row pitch (32 + 4 floats)
+constexpr int NB = 9 * 16;                // weight rows per chunk: 9 taps x 16 columns
+constexpr int HALO_F4 = NPX * 8;          // float4 per halo chunk
+constexpr int B_F4 = NB * 8;
+constexpr int PH = (HALO_F4 + 255) / 256; // 6
+constexpr int PBW = (B_F4 + 255) / 256;   // 5
+
+__global__ __launch_bounds__(256) void deconv3_halo_kernel(
+    const float* __restrict__ in, const float* __restrict__ w /*[C/32][9][16][32]*/,
+    const float* __restrict__ bias, float* __restrict__ out, int B, int Hi, int Wi, int C, int Ho,
+    int Wo, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float Hs[NPX * PIT];
+  __shared__ __attribute__((aligned(16))) float Bs[NB * PIT];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int bid = blockIdx.x;
+  const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
+  const int ty0 = (bid % tiles_y) * TH;
+  const int b = bid / tiles_y;
+  const int nchunk = C / 32;
+
+  // halo gather metadata (loop-invariant): byte offset of the pixel or -1 (zero padding)
+  long long hoff[PH];
+#pragma unroll
+  for (int k = 0; k < PH; ++k) {
+    const int f = tid + 256 * k;
+    hoff[k] = -1;
+    if (f < HALO_F4) {
+      const int px = f >> 3, c4 = f & 7;
+      const int hy = px / HW, hx = px - hy * HW;
+      const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+      if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi)
+        hoff[k] = ((long long)(b * Hi + iy) * Wi + ix) * C + c4 * 4;
+    }
+  }
+  f32x4 rh[PH], rw[PBW];
+  auto gload = [&](int c) {
+#pragma unroll
+    for (int k = 0; k < PH; ++k)
+      rh[k] = hoff[k] >= 0 ? *reinterpret_cast<const f32x4*>(in + hoff[k] + c * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < PBW; ++k) {
+      const int f = tid + 256 * k;
+      if (f < B_F4) rw[k] = *reinterpret_cast<const f32x4*>(w + (size_t)c * NB * 32 + f * 4);
+    }
+  };
+
+  f32x4 acc[2];
+  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc[1] = acc[0];
+  const int li = lane & 15, g = lane >> 4;
+  gload(0);
+  for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+    for (int k = 0; k < PH; ++k) {
+      const int f = tid + 256 * k;
+      if (f < HALO_F4) *reinterpret_cast<f32x4*>(&Hs[(f >> 3) * PIT + (f & 7) * 4]) = rh[k];
+    }
+#pragma unroll
+    for (int k = 0; k < PBW; ++k) {
+      const int f = tid + 256 * k;
+      if (f < B_F4) *reinterpret_cast<f32x4*>(&Bs[(f >> 3) * PIT + (f & 7) * 4]) = rw[k];
+    }
+    __syncthreads();
+    if (c + 1 < nchunk) gload(c + 1);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(&Bs[(t * 16 + li) * PIT + q * 16 + g * 4]);
+        f32x4 af[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int hy = 2 * wid + s + dy + 1, hx = li + dx + 1;
+          af[s] = *reinterpret_cast<const f32x4*>(&Hs[(hy * HW + hx) * PIT + q * 16 + g * 4]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][r], bf[r], acc[s], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // D layout of 16x16x4: column (n) = lane & 15, row (position within the 16-wide tile row) = 4*(lane>>4) + reg
+  const int n = li;
+  if (n < 12) {
+    const int pp = n / 3, ch = n - pp * 3;
+    const float bv = bias ? bias[ch] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int iy = ty0 + 2 * wid + s;
+      if (iy >= Hi) continue;
+      const int oy = 2 * iy + (pp >> 1);
+      if (oy >= Ho) continue;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ix = tx0 + 4 * g + reg;
+        const int ox = 2 * ix + (pp & 1);
+        if (ix < Wi && ox < Wo) out[((size_t)(b * Ho + oy) * Wo + ox) * 3 + ch] = acc[s][reg] + bv;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int launch_deconv3_halo(const float* in, const float* w, const float* bias, float* out, int B,
+                        int Hi, int Wi, int C, int Ho, int Wo, hipStream_t stream) {
+  const int tiles_x = (Wi + TW - 1) / TW, tiles_y = (Hi + TH - 1) / TH;
+  hipLaunchKernelGGL(deconv3_halo_kernel, dim3(B * tiles_x * tiles_y), dim3(256), 0, stream, in, w,
+                     bias, out, B, Hi, Wi, C, Ho, Wo, tiles_x, tiles_y);
+  return (int)hipGetLastError();
+}

@@ -73,6 +73,8 @@ struct sga_handle {
   float* gs_bias[4] = {nullptr}; float* gs_beta[3] = {nullptr};
   float* ha_bias[3] = {nullptr}; float* hs_bias[3] = {nullptr};
   float* eb_packed = nullptr;
+  float* gs3_halo_w = nullptr;   // C->3 layer packed for deconv3.hip: [C/32][9][16][32]
+  bool gs3_generic = false;      // SGA_GS3_GENERIC=1: use the generic gather-GEMM for the C->3 layer
   std::vector<void*> owned;      // every hipMalloc'd block
 
   // ---- workspace ----
@@ -444,6 +446,22 @@ int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float*
 // C->3 transposed conv (combined phases): [B,Hi,Wi,C] -> out [B,Ho,Wo,3] cropped to (Ho,Wo)
 int deconv_to3(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int B,
                int Hi, int Wi, int Ho, int Wo, float* out, hipStream_t st) {
+  if (!h->gs3_generic) {
+    sga_handle::ProfRec r;
+    if (h->profiling) {
+      r.flops = 2.0 * B * Hi * Wi * 25.0 * pc.Kc * 3.0;
+      snprintf(r.name, sizeof(r.name), h->profile_by_layer ? "%s deconv3_halo_kernel" : "deconv3_halo_kernel", h->cur_tag);
+      HIPCHK(h, hipEventCreate(&r.a));
+      HIPCHK(h, hipEventCreate(&r.b));
+      HIPCHK(h, hipEventRecord(r.a, st));
+    }
+    HIPCHK(h, launch_deconv3_halo(in, h->gs3_halo_w, bias, out, B, Hi, Wi, pc.Kc, Ho, Wo, st));
+    if (h->profiling) {
+      HIPCHK(h, hipEventRecord(r.b, st));
+      h->prof.push_back(r);
+    }
+    return SGA_OK;
+  }
   ConvArgs a = base_args(pc, B, Hi, Wi);
   a.in = in; a.out = out; a.bias = bias;
   a.Hin = Hi; a.Win = Wi; a.Hout = Ho; a.Wout = Wo;
@@ -689,6 +707,30 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     TRY(upload(h, &h->gs_bias[i], w->gs_bias[i], C));
   }
   TRY(pack_shuffle3(h, h->gs_f[3], w->gs_kernel[3], C));
+  {
+    // same tap/column mapping as pack_shuffle3, chunk-major for the halo kernel
+    std::vector<float> hw((size_t)(C / 32) * 9 * 16 * 32, 0.f);
+    const float* K = w->gs_kernel[3];
+    for (int c = 0; c < C / 32; ++c)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int t = (dy + 1) * 3 + (dx + 1);
+          for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+              const int ky = py + 2 - 2 * dy, kx = px + 2 - 2 * dx;
+              if (ky < 0 || ky > 4 || kx < 0 || kx > 4) continue;
+              for (int ch = 0; ch < 3; ++ch) {
+                const int n = (py * 2 + px) * 3 + ch;
+                for (int k = 0; k < 32; ++k)
+                  hw[(((size_t)c * 9 + t) * 16 + n) * 32 + k] =
+                      K[(((size_t)ky * 5 + kx) * C + c * 32 + k) * 3 + ch];
+              }
+            }
+        }
+    TRY(upload(h, &h->gs3_halo_w, hw.data(), hw.size()));
+    const char* e3 = getenv("SGA_GS3_GENERIC");
+    h->gs3_generic = e3 && e3[0] == '1';
+  }
   TRY(pack_smallc(h, h->gs_b[3], w->gs_kernel[3], C, true));
   TRY(upload(h, &h->gs_bias[3], w->gs_bias[3], 3));
   // ---- hyper-analysis ----

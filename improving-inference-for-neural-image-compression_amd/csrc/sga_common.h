@@ -97,3 +97,7 @@ int launch_splitk_reduce(const float* part, int ksplit, long long slab, long lon
 int conv_pick_bn(int cout, int epi);
 // kernel symbol (as rocprofv3 prints it) that launch_conv will use for these args
 void conv_kernel_name(const ConvArgs& a, char* out, int len);
+
+// C -> 3 transposed 5x5/2 conv, halo-tiled (deconv3.hip); w packed [C/32][9 taps][16][32]
+int launch_deconv3_halo(const float* in, const float* w, const float* bias, float* out, int B,
+                        int Hi, int Wi, int C, int Ho, int Wo, hipStream_t stream);
