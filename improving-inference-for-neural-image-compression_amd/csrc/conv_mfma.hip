@@ -56,16 +56,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
   const int chunk = tid & 7, lrow = tid >> 3;
 
   int bid = blockIdx.x;
-  int split = 0;
+  int split = 0, nsplit = 1, phase, mt, nt;
   if (a.ksplit > 1) {
-    const int tiles_total = a.nphase * a.tiles_per_phase * a.ntiles_n;
-    split = bid / tiles_total;
-    bid -= split * tiles_total;
+    phase = 0;
+    while (phase + 1 < a.nphase && bid >= a.blk_begin[phase + 1]) ++phase;
+    bid -= a.blk_begin[phase];
+    const int tiles = a.tiles_per_phase * a.ntiles_n;
+    nsplit = a.nsplit[phase];
+    split = bid / tiles;
+    bid -= split * tiles;
+    nt = bid % a.ntiles_n;
+    mt = bid / a.ntiles_n;
+  } else {
+    nt = bid % a.ntiles_n;
+    bid /= a.ntiles_n;
+    phase = bid / a.tiles_per_phase;
+    mt = bid - phase * a.tiles_per_phase;
   }
-  const int nt = bid % a.ntiles_n;
-  bid /= a.ntiles_n;
-  const int phase = bid / a.tiles_per_phase;
-  const int mt = bid - phase * a.tiles_per_phase;
   const ConvPhase ph = a.ph[phase];
   const int Mtot = a.B * a.Hg * a.Wg;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -158,9 +165,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
   const int nchunk = a.Cin / BK;
   const int nsteps_all = ph.ntaps * nchunk;
   int k_begin = 0, k_end = nsteps_all;
-  if (a.ksplit > 1) {
-    k_begin = (int)((long long)split * nsteps_all / a.ksplit);
-    k_end = (int)((long long)(split + 1) * nsteps_all / a.ksplit);
+  if (nsplit > 1) {
+    k_begin = (int)((long long)split * nsteps_all / nsplit);
+    k_end = (int)((long long)(split + 1) * nsteps_all / nsplit);
   }
   int tapi = k_begin / nchunk, ci0 = (k_begin - tapi * nchunk) * BK;
   if (k_begin < k_end) gload(tapi, ci0);
@@ -303,26 +310,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
   }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, int ksplit, long long slab,
-                                     long long n4, int cout, int epi,
-                                     const float* __restrict__ bias, const float* __restrict__ aux0,
-                                     float* __restrict__ out) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+struct ReduceArgs {
+  const float* part; long long slab; long long n4;
+  int cout, epi, hout, wout, s_out;
+  int nsplit[4];
+  const float* bias; const float* aux0; float* out;
+};
+
+__global__ void splitk_reduce_kernel(const ReduceArgs r) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < r.n4;
        i += (long long)gridDim.x * blockDim.x) {
     const long long e = i * 4;
-    f32x4 acc = ld4(part + e);
-    for (int s = 1; s < ksplit; ++s) acc += ld4(part + (size_t)s * slab + e);   // fixed order
-    const int c = (int)(e % cout);
-    if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && bias) acc += ld4(bias + c);
-    if (epi == EPI_BIAS_RELU) {
+    const int c = (int)(e % r.cout);
+    int S = r.nsplit[0];
+    if (r.s_out == 2) {      // transposed conv: the split factor depends on the sub-pixel phase
+      const long long pix = e / r.cout;
+      const int ox = (int)(pix % r.wout), oy = (int)((pix / r.wout) % r.hout);
+      S = r.nsplit[(oy & 1) * 2 + (ox & 1)];
+    }
+    f32x4 acc = ld4(r.part + e);
+    for (int s = 1; s < S; ++s) acc += ld4(r.part + (size_t)s * r.slab + e);   // fixed order
+    if ((r.epi == EPI_BIAS || r.epi == EPI_BIAS_RELU) && r.bias) acc += ld4(r.bias + c);
+    if (r.epi == EPI_BIAS_RELU) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[k] = fmaxf(acc[k], 0.f);
-    } else if (epi == EPI_RELU_MASK) {
-      const f32x4 m = ld4(aux0 + e);
+    } else if (r.epi == EPI_RELU_MASK) {
+      const f32x4 m = ld4(r.aux0 + e);
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[k] = m[k] > 0.f ? acc[k] : 0.f;
     }
-    *reinterpret_cast<f32x4*>(out + e) = acc;
+    *reinterpret_cast<f32x4*>(r.out + e) = acc;
   }
 }
 
@@ -340,7 +357,11 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  const int grid = a.nphase * a.tiles_per_phase * a.ntiles_n * (a.ksplit > 1 ? a.ksplit : 1);
+  int grid = a.nphase * a.tiles_per_phase * a.ntiles_n;
+  if (a.ksplit > 1) {
+    grid = 0;
+    for (int p = 0; p < a.nphase; ++p) grid += a.tiles_per_phase * a.ntiles_n * a.nsplit[p];
+  }
   if (grid <= 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC>), dim3(grid), dim3(NT), lds,
                      stream, a);
@@ -386,15 +407,17 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
            a.smallc ? "true" : "false");
 }
 
-int launch_splitk_reduce(const float* part, int ksplit, long long slab, long long n, int cout,
-                         int epi, const float* bias, const float* aux0, float* out,
-                         hipStream_t stream) {
-  const long long n4 = n / 4;
-  long long g = (n4 + 255) / 256;
+int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream) {
+  ReduceArgs r;
+  r.part = a.part; r.slab = a.slab; r.n4 = n / 4;
+  r.cout = a.Cout; r.epi = a.epi; r.hout = a.Hout; r.wout = a.Wout; r.s_out = a.s_out;
+  for (int p = 0; p < 4; ++p) r.nsplit[p] = a.nsplit[p] > 0 ? a.nsplit[p] : 1;
+  // the phase table is ordered heaviest-first == (py,px) = (0,0),(0,1),(1,0),(1,1): index py*2+px
+  r.bias = a.bias; r.aux0 = a.aux0; r.out = a.out;
+  long long g = (r.n4 + 255) / 256;
   if (g > 4096) g = 4096;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, part, ksplit,
-                     slab, n4, cout, epi, bias, aux0, out);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, r);
   return (int)hipGetLastError();
 }
 

@@ -139,23 +139,37 @@ namespace {
 // Split-K factor for a launch whose tile grid under-fills the chip (256 CUs): spread the K walk
 // of each tile over S workgroups so that ~2 workgroups per CU are resident and the serial
 // K-chain per workgroup is S times shorter (deterministic slab reduce afterwards).
-int pick_ksplit(const sga_handle* h, const ConvArgs& a) {
+int pick_ksplit(const sga_handle* h, ConvArgs& a) {
+  for (int p = 0; p < 4; ++p) { a.nsplit[p] = 1; a.blk_begin[p] = 0; }
   if (h->no_splitk || a.smallc || a.pro != PRO_NONE) return 1;
   if (a.epi != EPI_BIAS && a.epi != EPI_BIAS_RELU && a.epi != EPI_RELU_MASK) return 1;
   if (a.out_coff != 0 || a.out_cs != a.Cout || (a.Cout & 3)) return 1;
-  const int blocks = a.nphase * a.tiles_per_phase * a.ntiles_n;
+  const int tiles = a.tiles_per_phase * a.ntiles_n;
+  const int blocks = a.nphase * tiles;
   if (blocks > 256 || (blocks == 256 && a.nphase == 1)) return 1;
-  int min_steps = 1 << 30;
+  // target: ~512 workgroups of (nearly) equal K length
+  long long total_steps = 0;
+  int steps[4] = {0, 0, 0, 0};
   for (int p = 0; p < a.nphase; ++p) {
-    const int st = a.ph[p].ntaps * (a.Cin / 32);
-    if (st < min_steps) min_steps = st;
+    steps[p] = a.ph[p].ntaps * (a.Cin / 32);
+    total_steps += (long long)steps[p] * tiles;
   }
-  int S = 512 / blocks;
-  if (S > min_steps / 2) S = min_steps / 2;      // at least 2 K-steps per split
+  int T = (int)((total_steps + 511) / 512);      // K-steps per workgroup
+  if (T < 2) T = 2;
   const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
   const long long cap = (long long)h->cur_part->cap / n_out;
-  if (S > cap) S = (int)cap;
-  return S < 2 ? 1 : S;
+  int smax = 1, begin = 0;
+  for (int p = 0; p < a.nphase; ++p) {
+    int S = (steps[p] + T / 2) / T;
+    if (S > steps[p] / 2) S = steps[p] / 2;
+    if (S > cap) S = (int)cap;
+    if (S < 1) S = 1;
+    a.nsplit[p] = S;
+    a.blk_begin[p] = begin;
+    begin += tiles * S;
+    if (S > smax) smax = S;
+  }
+  return smax;
 }
 
 // every MFMA convolution goes through here (so it can be timed)
@@ -182,9 +196,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st) {
     HIPCHK(h, hipEventRecord(r.b, st));
     h->prof.push_back(r);
   }
-  if (a.ksplit > 1)
-    HIPCHK(h, launch_splitk_reduce(a.part, a.ksplit, a.slab, n_out, a.Cout, a.epi, a.bias, a.aux0,
-                                   a.out, st));
+  if (a.ksplit > 1) HIPCHK(h, launch_splitk_reduce(a, n_out, st));
   if (h->profiling && h->profile_by_layer) {    // layer-level stats: conv + its reduce
     HIPCHK(h, hipEventRecord(r.b, st));
     h->prof.push_back(r);
@@ -817,7 +829,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     if (msssim_init() != 0) return fail(SGA_ERR_HIP);
   }
   TRY(alloc_buf(h, h->scratch, 8 + B * 8));
-  TRY(alloc_buf(h, h->part, (size_t)16 << 20));      // 64 MiB
+  TRY(alloc_buf(h, h->part, (size_t)48 << 20));      // 192 MiB
   TRY(alloc_buf(h, h->partB, (size_t)8 << 20));      // 32 MiB
   h->cur_part = &h->part;
   TRY(alloc_buf(h, h->trace, (size_t)kMaxIts * 4));

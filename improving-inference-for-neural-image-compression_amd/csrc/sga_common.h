@@ -80,7 +80,9 @@ struct ConvArgs {
   // split-K: grid = tiles x ksplit; split s multiplies K-steps [s*n/S, (s+1)*n/S) of its phase and
   // writes the raw accumulators to part + s*slab (output geometry); a fixed-order reduce kernel
   // then sums the slabs and applies the epilogue (deterministic, no atomics).
-  int ksplit;
+  int ksplit;              // max over phases of nsplit[] (1 = no split)
+  int nsplit[4];           // per-phase split factor: phases differ in tap count (9/6/6/4), so each
+  int blk_begin[4];        //   gets splits in proportion and all workgroups walk ~equal K
   long long slab;
   float* part;
   ConvPhase ph[4];
@@ -90,9 +92,7 @@ struct ConvArgs {
 // returns hipError_t
 int launch_conv(const ConvArgs& a, hipStream_t stream);
 // out[i] = epi(sum_s part[s*slab + i]) over n floats, channel = i % cout (n, cout multiples of 4)
-int launch_splitk_reduce(const float* part, int ksplit, long long slab, long long n, int cout,
-                         int epi, const float* bias, const float* aux0, float* out,
-                         hipStream_t stream);
+int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream);
 // tile sizes chosen for an output width (host-side, also used to size Npad when packing)
 int conv_pick_bn(int cout, int epi);
 // kernel symbol (as rocprofv3 prints it) that launch_conv will use for these args
