@@ -38,6 +38,8 @@ class SGACodec:
         self.C = int(num_filters)
         self.bits_back = bool(bits_back)
         check_weights(weights, self.C, bits_back)
+        self._weights_for_ec = {k: v for k, v in weights.items() if k.startswith("eb.")}
+        self._ec = None
         self.max_batch, self.max_height, self.max_width = int(max_batch), int(max_height), int(max_width)
         torch.cuda.set_device(self.device)
         # a dedicated non-null stream: hipGraph capture is not allowed on the legacy null stream
@@ -275,6 +277,47 @@ class SGACodec:
                                                      _ptr(p), _ptr(dp), s), "sga_op_factorized_density")
         self._exit()
         return p, dp
+
+    # ---- actual bitstreams (mbt2018.py:84-85,211-222) ------------------------------
+    def hyper_synthesis(self, z_hat, yh, yw):
+        """(mu, sigma) = split(h_s(z_hat)), sigma = exp(.), cropped to the y grid (sga.py:107-108,
+        126-128); same device kernels on the encoder and decoder side."""
+        t = self.layer_fwd("HS2", self.layer_fwd("HS1", self.layer_fwd("HS0", z_hat)))
+        t = t[:, :yh, :yw, :]
+        return t[..., :self.C].contiguous(), torch.exp(t[..., self.C:]).contiguous()
+
+    def _entropy_coder(self, weights=None):
+        if getattr(self, "_ec", None) is None:
+            from .entropy_coding import EntropyCoder
+            self._ec = EntropyCoder(weights if weights is not None else self._weights_for_ec)
+        return self._ec
+
+    def compress_latents(self, x_shape, y_hat, z_hat) -> bytes:
+        """Entropy-code (y_hat, z_hat) of a batch into one byte string (cf. tfc.PackedTensors)."""
+        from . import entropy_coding as ec
+        coder = self._entropy_coder()
+        y_hat, z_hat = self._t(y_hat), self._t(z_hat)
+        mu, sigma = self.hyper_synthesis(z_hat, y_hat.shape[1], y_hat.shape[2])
+        zb = coder.encode_z(z_hat.cpu().numpy())
+        yb = coder.encode_y(y_hat.cpu().numpy(), mu.cpu().numpy(), sigma.cpu().numpy())
+        return ec.pack(tuple(x_shape), tuple(y_hat.shape), tuple(z_hat.shape), zb, yb)
+
+    def decompress_latents(self, blob: bytes):
+        """-> (x_shape, y_hat, z_hat): z first, then (mu, sigma) = h_s(z_hat), then y."""
+        from . import entropy_coding as ec
+        coder = self._entropy_coder()
+        x_shape, y_shape, z_shape, zb, yb = ec.unpack(blob)
+        z_hat = self._t(coder.decode_z(zb, z_shape))
+        mu, sigma = self.hyper_synthesis(z_hat, y_shape[1], y_shape[2])
+        y_hat = self._t(coder.decode_y(yb, mu.cpu().numpy(), sigma.cpu().numpy()))
+        return x_shape, y_hat, z_hat
+
+    def reconstruct(self, y_hat, H, W):
+        """x_hat = clip(g_s(y_hat)) cropped to HxW (mbt2018.py:283-288)."""
+        t = self._t(y_hat)
+        for name in ("GS0", "GS1", "GS2", "GS3"):
+            t = self.layer_fwd(name, t)
+        return torch.clamp(t[:, :H, :W, :], 0, 1)
 
     # ---- measurement ---------------------------------------------------------------------------
     def profile_begin(self):

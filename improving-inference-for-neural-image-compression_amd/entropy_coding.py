@@ -1,0 +1,228 @@
+"""Actual entropy coding of the quantised latents (y_hat, z_hat) -- SURVEY.md 8(f)-4.
+
+The reference turns latents into bytes only in `mbt2018.py` (`entropy_bottleneck.compress(z)`,
+`conditional_bottleneck.compress(y)`, `tfc.PackedTensors`; mbt2018.py:84-85,211-222) through
+tensorflow-compression's C++ range coder; `sga.py` reports estimated rates only.  This module
+provides the counterpart for this build: quantised CDF tables from the same two entropy models,
+a rANS core in C (`csrc_cpu/rans.c` -> librans.so) and a small container.  The byte format is
+this build's own (tfc's `.tfci` cannot be reproduced without tfc).
+
+  z_hat : per-channel factorized prior mass p_c(k) (tfc EntropyBottleneck._likelihood, restated
+          from learned_prior.py:96-121), one table per channel, integers outside the table's
+          range escape-coded.
+  y_hat : N(mu, sigma) conv U(-.5,.5) (utils.py:80-102).  Tables are indexed by the scale level
+          (the reference's scale_table: 64 log-spaced levels in [0.11, 256], sga.py:24-26,129) and
+          by the fractional part of mu quantised to 1/8; the coded symbol is y_hat - round(mu).
+          (SGA's y_hat = round(y) is not mean-centred, unlike tfc's round(y - mu) + mu.)
+
+Probabilities use 16 bits, every in-range symbol keeps frequency >= 1, tail mass goes to the
+escape symbol (tfc: tail_mass = 1e-9 + Golomb overflow codes).  Decoding needs bit-identical
+(mu, sigma) on both sides: compute them with the same kernels (SGACodec.hyper_synthesis).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import struct
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "librans.so")
+PRECISION = 16
+TOTAL = 1 << PRECISION
+SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64          # sga.py:24-26
+MEAN_BINS = 8
+MAGIC = b"SGAC"
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: run __graft_entry__.build()")
+        lib = C.CDLL(LIB_PATH)
+        i32p, u32p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+        lib.rans_encode.restype = C.c_size_t
+        lib.rans_encode.argtypes = [i32p, i32p, C.c_size_t, u32p, i32p, i32p, C.c_int, u8p, C.c_size_t]
+        lib.rans_decode.restype = C.c_int
+        lib.rans_decode.argtypes = [u8p, C.c_size_t, i32p, C.c_size_t, u32p, i32p, i32p, C.c_int, i32p]
+        _lib = lib
+    return _lib
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+# ---------------------------------------------------------------------------------------------
+# probability models (numpy, float64) -> quantised CDF tables
+# ---------------------------------------------------------------------------------------------
+def factorized_mass(w: dict, ks: np.ndarray) -> np.ndarray:
+    """p_c(k) for integer grid ks [K] and every channel: returns [K, C] (learned_prior.py:96-121 +
+    the box mass with the sign trick of tfc EntropyBottleneck._likelihood)."""
+    Cn = w["eb.m0"].shape[0]
+
+    def logits(v):                       # v [K] -> [K, C]
+        t = np.broadcast_to(v[None, None, :], (Cn, 1, v.size)).astype(np.float64)
+        for k in range(4):
+            t = np.matmul(w[f"eb.m{k}"].astype(np.float64), t) + w[f"eb.b{k}"].astype(np.float64)
+            if k < 3:
+                t = t + w[f"eb.f{k}"].astype(np.float64) * np.tanh(t)
+        return t[:, 0, :].T
+
+    lo, up = logits(ks - 0.5), logits(ks + 0.5)
+    sg = -np.sign(lo + up)
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+    return np.abs(sig(sg * up) - sig(sg * lo))
+
+
+def _phi(x):
+    return 0.5 * np.vectorize(math.erfc)(-x / math.sqrt(2.0))
+
+
+def quantise_pmf(pmf: np.ndarray) -> np.ndarray:
+    """pmf over regular symbols (sum <= 1; the remainder is the escape mass) -> CDF of len+2 uint32
+    entries (regular symbols + escape), total exactly 1<<16, every frequency >= 1."""
+    n = pmf.size
+    esc = max(1.0 - float(pmf.sum()), 0.0)
+    p = np.concatenate([pmf, [esc]])
+    f = np.maximum(np.round(p * TOTAL).astype(np.int64), 1)
+    # fix the total by adjusting the largest entries
+    diff = int(TOTAL - f.sum())
+    order = np.argsort(-f)
+    i = 0
+    while diff != 0:
+        j = order[i % (n + 1)]
+        step = 1 if diff > 0 else -1
+        if f[j] + step >= 1:
+            f[j] += step
+            diff -= step
+        i += 1
+    cdf = np.zeros(n + 2, np.uint32)
+    cdf[1:] = np.cumsum(f)
+    assert cdf[-1] == TOTAL
+    return cdf
+
+
+class EntropyCoder:
+    def __init__(self, weights: dict, z_max_abs: int = 96, tail: float = 2.0 ** -14):
+        self.C = weights["eb.m0"].shape[0]
+        self.scale_table = np.exp(np.linspace(math.log(SCALES_MIN), math.log(SCALES_MAX), SCALES_LEVELS))
+        tables, lens, offs = [], [], []
+        # ---- z: one table per channel -------------------------------------------------------
+        ks = np.arange(-z_max_abs, z_max_abs + 1, dtype=np.float64)
+        mass = factorized_mass(weights, ks)                    # [K, C]
+        for c in range(self.C):
+            m = mass[:, c]
+            keep = np.nonzero(m >= tail / 8)[0]
+            lo, hi = (keep[0], keep[-1]) if keep.size else (z_max_abs, z_max_abs)
+            tables.append(quantise_pmf(m[lo:hi + 1]))
+            lens.append(hi - lo + 2)
+            offs.append(int(ks[lo]))
+        self.z_tab0 = 0
+        # ---- y: scale level x mean-fraction bin -----------------------------------------------
+        self.y_tab0 = len(tables)
+        for s in self.scale_table:
+            R = int(math.ceil(6.0 * s + 1.0))                    # +-6 sigma, rest escapes
+            r = np.arange(-R, R + 1, dtype=np.float64)
+            for j in range(MEAN_BINS):
+                f = (j + 0.5) / MEAN_BINS - 0.5
+                pm = _phi((r + 0.5 - f) / s) - _phi((r - 0.5 - f) / s)
+                tables.append(quantise_pmf(pm))
+                lens.append(r.size + 1)
+                offs.append(-R)
+        self.stride = max(t.size for t in tables)
+        self.cdf = np.zeros((len(tables), self.stride), np.uint32)
+        for i, t in enumerate(tables):
+            self.cdf[i, :t.size] = t
+            self.cdf[i, t.size:] = TOTAL
+        self.lens = np.asarray(lens, np.int32)
+        self.offs = np.asarray(offs, np.int32)
+
+    # ---- symbol/table preparation ---------------------------------------------------------------
+    def _y_symbols(self, y_hat, mu, sigma):
+        mu = np.asarray(mu, np.float32)
+        r0 = np.rint(mu)
+        frac = (mu - r0).astype(np.float64)
+        jbin = np.clip(np.floor((frac + 0.5) * MEAN_BINS), 0, MEAN_BINS - 1).astype(np.int32)
+        sg = np.maximum(np.asarray(sigma, np.float64), SCALES_MIN)
+        lvl = np.clip(np.searchsorted(self.scale_table, sg, side="left"), 0, SCALES_LEVELS - 1).astype(np.int32)
+        tab = (self.y_tab0 + lvl * MEAN_BINS + jbin).astype(np.int32)
+        return r0.astype(np.int32), tab
+
+    def _run_encode(self, sym, tab):
+        lib = _load()
+        sym = np.ascontiguousarray(sym.reshape(-1), np.int32)
+        tab = np.ascontiguousarray(tab.reshape(-1), np.int32)
+        cap = 16 + 8 * sym.size
+        out = np.zeros(cap, np.uint8)
+        n = lib.rans_encode(_ptr(sym, C.c_int32), _ptr(tab, C.c_int32), sym.size, _ptr(self.cdf, C.c_uint32),
+                            _ptr(self.lens, C.c_int32), _ptr(self.offs, C.c_int32), self.stride,
+                            _ptr(out, C.c_uint8), cap)
+        if n == 0:
+            raise RuntimeError("rans_encode: output buffer overflow")
+        return out[cap - n:].tobytes()
+
+    def _run_decode(self, data: bytes, tab):
+        lib = _load()
+        tab = np.ascontiguousarray(tab.reshape(-1), np.int32)
+        buf = np.frombuffer(data, np.uint8).copy()
+        sym = np.zeros(tab.size, np.int32)
+        rc = lib.rans_decode(_ptr(buf, C.c_uint8), buf.size, _ptr(tab, C.c_int32), tab.size,
+                             _ptr(self.cdf, C.c_uint32), _ptr(self.lens, C.c_int32),
+                             _ptr(self.offs, C.c_int32), self.stride, _ptr(sym, C.c_int32))
+        if rc != 0:
+            raise ValueError("rans_decode: corrupt stream")
+        return sym
+
+    # ---- public API -----------------------------------------------------------------------------
+    def encode_z(self, z_hat) -> bytes:
+        z = np.rint(np.asarray(z_hat)).astype(np.int32)
+        tab = np.broadcast_to(np.arange(self.C, dtype=np.int32), z.shape)
+        return self._run_encode(z, tab)
+
+    def decode_z(self, data: bytes, shape) -> np.ndarray:
+        tab = np.broadcast_to(np.arange(self.C, dtype=np.int32), shape)
+        return self._run_decode(data, tab).reshape(shape).astype(np.float32)
+
+    def encode_y(self, y_hat, mu, sigma) -> bytes:
+        r0, tab = self._y_symbols(y_hat, mu, sigma)
+        return self._run_encode(np.rint(np.asarray(y_hat)).astype(np.int32) - r0, tab)
+
+    def decode_y(self, data: bytes, mu, sigma) -> np.ndarray:
+        r0, tab = self._y_symbols(None, mu, sigma)
+        return (self._run_decode(data, tab).reshape(r0.shape) + r0).astype(np.float32)
+
+    def ideal_bits_y(self, y_hat, mu, sigma) -> float:
+        """-sum log2 of the QUANTISED model probabilities actually used (for tests)."""
+        r0, tab = self._y_symbols(y_hat, mu, sigma)
+        idx = (np.rint(np.asarray(y_hat)).astype(np.int64) - r0 - self.offs[tab]).reshape(-1)
+        tab = tab.reshape(-1)
+        ln = self.lens[tab]
+        esc = (idx < 0) | (idx >= ln - 1)
+        idx = np.where(esc, ln - 1, idx)
+        f = self.cdf[tab, idx + 1].astype(np.float64) - self.cdf[tab, idx]
+        return float(-np.log2(f / TOTAL).sum() + 32.0 * esc.sum())
+
+
+def pack(x_shape, y_shape, z_shape, z_bytes: bytes, y_bytes: bytes) -> bytes:
+    """Container (cf. tfc.PackedTensors, mbt2018.py:211-214): magic, shapes, two length-prefixed streams."""
+    head = MAGIC + struct.pack("<3I4I4I", *x_shape, *y_shape, *z_shape)
+    return head + struct.pack("<I", len(z_bytes)) + z_bytes + struct.pack("<I", len(y_bytes)) + y_bytes
+
+
+def unpack(blob: bytes):
+    if blob[:4] != MAGIC:
+        raise ValueError("not an SGAC stream")
+    v = struct.unpack("<3I4I4I", blob[4:48])
+    x_shape, y_shape, z_shape = v[:3], v[3:7], v[7:11]
+    p = 48
+    (nz,) = struct.unpack("<I", blob[p:p + 4]); p += 4
+    z_bytes = blob[p:p + nz]; p += nz
+    (ny,) = struct.unpack("<I", blob[p:p + 4]); p += 4
+    y_bytes = blob[p:p + ny]
+    return x_shape, y_shape, z_shape, z_bytes, y_bytes

@@ -1,0 +1,70 @@
+"""CPU tests of the entropy coder: exact decode round trip, coded size close to
+the model's ideal code length, escape path, corrupt-stream detection."""
+import numpy as np
+import pytest
+
+import sga_amd
+from sga_amd import entropy_coding as ec
+
+
+@pytest.fixture(scope="module")
+def coder():
+    return ec.EntropyCoder(sga_amd.make_synthetic_weights(64, seed=0))
+
+
+def test_tables_are_valid(coder):
+    for t in range(coder.cdf.shape[0]):
+        c = coder.cdf[t, :coder.lens[t] + 1].astype(np.int64)
+        assert c[0] == 0 and c[-1] == ec.TOTAL and (np.diff(c) >= 1).all()
+
+
+def test_z_round_trip_and_size(coder):
+    rng = np.random.RandomState(0)
+    z = np.rint(rng.standard_normal((2, 3, 4, 64)) * 6).astype(np.float32)
+    z[0, 0, 0, :4] = [500, -321, 97, -97]                        # outside every table: escapes
+    blob = coder.encode_z(z)
+    assert np.array_equal(coder.decode_z(blob, z.shape), z)
+    w = sga_amd.make_synthetic_weights(64, seed=0)
+    ks = np.arange(-96, 97, dtype=np.float64)
+    mass = ec.factorized_mass(w, ks)
+    zi = z.astype(np.int64).reshape(-1, 64)
+    inr = np.abs(zi) <= 96
+    ideal = -np.log2(mass[np.clip(zi, -96, 96) + 96, np.arange(64)[None, :]])[inr].sum() + 32 * (~inr).sum()
+    assert 8 * len(blob) < ideal * 1.03 + 64
+
+
+def test_y_round_trip_and_size(coder):
+    rng = np.random.RandomState(1)
+    shape = (2, 5, 7, 64)
+    mu = (rng.standard_normal(shape) * 2).astype(np.float32)
+    sigma = np.exp(rng.standard_normal(shape) * 1.2).astype(np.float32)
+    sigma.reshape(-1)[:50] = 0.02                                 # below the 0.11 bound
+    sigma.reshape(-1)[50:60] = 300.0                              # above the table
+    y = np.rint(mu + sigma * rng.standard_normal(shape)).astype(np.float32)
+    y.reshape(-1)[100:104] = [4000, -4000, 1e5, -1e5]             # escapes
+    blob = coder.encode_y(y, mu, sigma)
+    assert np.array_equal(coder.decode_y(blob, mu, sigma), y)
+    ideal = coder.ideal_bits_y(y, mu, sigma)
+    assert ideal <= 8 * len(blob) <= ideal * 1.01 + 64            # rANS overhead is tiny
+    # quantising (sigma, frac(mu)) costs only a few % over the exact model
+    from math import erfc, sqrt
+    sb = np.maximum(sigma.astype(np.float64), 0.11)
+    d = np.abs(y - mu).astype(np.float64)
+    phi = np.vectorize(lambda t: 0.5 * erfc(-t / sqrt(2)))
+    p = np.maximum(phi((0.5 - d) / sb) - phi((-0.5 - d) / sb), 1e-9)
+    keep = np.ones(y.size, bool); keep[:60] = False; keep[100:104] = False
+    exact = -np.log2(p.reshape(-1)[keep]).sum()
+    yk, mk, sk = (a.reshape(-1)[keep] for a in (y, mu, sigma))
+    assert coder.ideal_bits_y(yk, mk, sk) < exact * 1.08 + 100
+
+
+def test_container_and_corruption(coder):
+    z = np.rint(np.random.RandomState(2).standard_normal((1, 2, 2, 64)) * 3).astype(np.float32)
+    zb = coder.encode_z(z)
+    blob = ec.pack((1, 64, 64), (1, 4, 4, 64), z.shape, zb, b"abc")
+    xs, ys, zs, zb2, yb2 = ec.unpack(blob)
+    assert xs == (1, 64, 64) and zs == z.shape and zb2 == zb and yb2 == b"abc"
+    with pytest.raises(ValueError):
+        ec.unpack(b"nope" + blob[4:])
+    with pytest.raises(ValueError):
+        coder.decode_z(zb[:3], z.shape)

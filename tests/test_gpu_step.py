@@ -238,3 +238,25 @@ def test_sibling_relaxations(mode, gpu_out_dir):
     assert rel_err(got["gy"].cpu().numpy(), ref["gy"].numpy()) < 1e-4
     assert rel_err(got["gz"].cpu().numpy(), ref["gz"].numpy()) < 1e-4
     assert abs(got["rd_loss"] - ref["rd_loss"]) <= 2e-5 * abs(ref["rd_loss"])
+
+
+def test_bitstream_round_trip(gpu_out_dir):
+    """Real bytes for (y_hat, z_hat): decode reproduces the latents exactly and the actual rate is
+    within a few % of the estimated rate (mbt2018.py:211-222 reports both)."""
+    from sga_amd.codec import metrics_to_dict
+    C, B, H, W = 64, 2, 64, 64
+    codec, orc, _ = setup(C, B, H, W)
+    x = image(B, H, W, seed=21)
+    y_hat, z_hat, met, _ = codec.run(x, 0.01, its=30, seed=2)
+    blob = codec.compress_latents((B, H, W), y_hat, z_hat)
+    xs, y2, z2 = codec.decompress_latents(blob)
+    assert tuple(xs) == (B, H, W)
+    assert torch.equal(y2, y_hat) and torch.equal(z2, z_hat)
+    m = metrics_to_dict(met)
+    actual_bpp = 8.0 * len(blob) / (B * H * W)
+    est_bpp = float(m["est_bpp"].mean())
+    report(gpu_out_dir, "bitstream", actual_bpp=actual_bpp, est_bpp=est_bpp, bytes=len(blob))
+    assert est_bpp * 0.98 < actual_bpp < est_bpp * 1.10 + 0.05
+    x_hat = codec.reconstruct(y2, H, W)
+    mse = ((x_hat * 255).round() - torch.as_tensor(x).cuda() * 255).pow(2).mean(dim=(1, 2, 3)).cpu().numpy()
+    assert np.allclose(mse, m["mse"], rtol=1e-3)
