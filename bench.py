@@ -101,11 +101,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
+    # test-only overrides (1-GPU boxes): SGA_BENCH_BACKEND=gloo SGA_BENCH_SHARE_DEVICE=1 let two ranks
+    # share cuda:0 so that the multi-process path can be smoke-tested without a multi-GPU node
+    backend = os.environ.get("SGA_BENCH_BACKEND", "nccl")
+    if os.environ.get("SGA_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
@@ -119,9 +127,10 @@ def main():
 
     def one_step(seed):
         y_hat, z_hat, met, _ = codec.run(x, args.lmbda, its=args.its, seed=seed)
-        if dist is not None:     # result gather: the only collective on this path
-            out = [torch.empty_like(met) for _ in range(world)]
-            dist.all_gather(out, met)
+        if dist is not None:     # result gather: the only collective on this path (RCCL)
+            src = met if backend == "nccl" else met.cpu()
+            out = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(out, src)
             met = torch.cat(out, 0)
         return met
 
@@ -140,7 +149,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     n_images = world * B * args.steps
