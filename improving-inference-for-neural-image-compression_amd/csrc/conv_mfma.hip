@@ -24,6 +24,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -33,8 +36,37 @@ constexpr int LDK = 36;  // LDS row pitch in floats (BK + 4)
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
 
-template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvArgs a) {
+// ---- precision mode "bf16x3" -------------------------------------------------------------------
+// An f32 value is the exact sum of three bf16 values (3 x 8 mantissa bits = the 24-bit mantissa):
+// x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m).  A product a*b is then the
+// sum of 9 bf16 x bf16 products (each exact in f32); dropping the three of order 2^-24 and below
+// (m*l, l*m, l*l) leaves 6 products whose f32-accumulated sum has the accuracy of an f32 FMA chain
+// (measured: 2.4e-7 max rel. error at K = 4800, vs 4.4e-7 for an f32 GEMM).  The bf16 matrix pipe
+// is 16x the f32 one, so 6 MFMAs per product are 2.67x faster than one f32 MFMA.
+constexpr int X3_PITCH = 80;     // bytes per LDS row per plane: 32 bf16 + 16 B pad (conflict-free b128 reads)
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));   // [15:0] = bf16(lo), [31:16] = bf16(hi), RNE
+  return r;
+}
+__device__ __forceinline__ float bf16_lo(unsigned pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned pk) { return __uint_as_float(pk & 0xffff0000u); }
+
+// 4 floats -> three planes of 4 packed bf16 (8 bytes each)
+__device__ __forceinline__ void split3(const f32x4 v, u32x2& h, u32x2& m, u32x2& l) {
+  h.x = cvt_pk_bf16(v.x, v.y);
+  h.y = cvt_pk_bf16(v.z, v.w);
+  const float r0 = v.x - bf16_lo(h.x), r1 = v.y - bf16_hi(h.x);
+  const float r2 = v.z - bf16_lo(h.y), r3 = v.w - bf16_hi(h.y);
+  m.x = cvt_pk_bf16(r0, r1);
+  m.y = cvt_pk_bf16(r2, r3);
+  l.x = cvt_pk_bf16(r0 - bf16_lo(m.x), r1 - bf16_hi(m.x));
+  l.y = cvt_pk_bf16(r2 - bf16_lo(m.y), r3 - bf16_hi(m.y));
+}
+
+template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3>
+__global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int RPP = NT / 8;                 // tile rows covered by one pass of the loaders
@@ -43,9 +75,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
   constexpr int PX = (PRO == PRO_IGDN_BWD) ? PA : 1;
 
   constexpr int CPITCH = TN * 32 + 4;         // epilogue staging pitch (floats) per wave row
-  constexpr int MAIN_FLOATS = (BM + BN) * LDK;
+  constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (BM + BN) * LDK;
   constexpr int EPI_FLOATS = WM * WN * 32 * CPITCH;
   constexpr int LDS_FLOATS = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
+  constexpr int PBX = X3 ? (BN * 12) / NT : 1;     // 16-byte pieces of the 3-plane weight tile per thread
+  static_assert(!X3 || (BN * 12) % NT == 0, "x3 loader mismatch");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + BM * LDK;
@@ -112,7 +146,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
     rowpix[r] = px;
   }
 
-  f32x4 ra[PA], rb[PB], ra1[PX], ra2[PX];
+  f32x4 ra[PA], rb[X3 ? 1 : PB], ra1[PX], ra2[PX];
+  u32x4 rbx[PBX];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
 
@@ -146,11 +181,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
         }
       }
     }
+    if constexpr (X3) {
+      // weight tile: BN rows x (3 planes x 32 bf16) = 192 contiguous bytes per row and K-step
+      const unsigned short* wb = a.w3 + (((size_t)tp.slab * a.Npad + n0) * (a.Cin / BK) + ci0 / BK) * 96;
 #pragma unroll
-    for (int p = 0; p < PB; ++p) {
-      const int n = n0 + p * RPP + lrow;
-      const size_t off = ((size_t)tp.slab * a.Npad + n) * a.Cin + ci0 + chunk * 4;
-      rb[p] = ld4(a.w + off);
+      for (int k = 0; k < PBX; ++k) {
+        const int f = tid + NT * k;
+        const int nl = f / 12, piece = f - nl * 12;
+        rbx[k] = *reinterpret_cast<const u32x4*>(wb + (size_t)nl * (a.Cin / BK) * 96 + piece * 8);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < PB; ++p) {
+        const int n = n0 + p * RPP + lrow;
+        const size_t off = ((size_t)tp.slab * a.Npad + n) * a.Cin + ci0 + chunk * 4;
+        rb[p] = ld4(a.w + off);
+      }
     }
   };
 
@@ -178,16 +224,37 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
 
   for (int ks = k_begin; ks < k_end; ++ks) {
     // ---- staged registers -> LDS (prologue transform fused here) ----------------------
+    char* const smem_b = reinterpret_cast<char*>(smem);
+    constexpr int A_PLANE = BM * X3_PITCH, B_PLANE = BN * X3_PITCH, B3_BASE = 3 * A_PLANE;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
       f32x4 v = ra[p];
       if constexpr (PRO == PRO_SQUARE) v = v * v;
       if constexpr (PRO == PRO_IGDN_BWD) v = v * ra2[p] / ra1[p];   // g * u / s
-      *reinterpret_cast<f32x4*>(&As[(p * RPP + lrow) * LDK + chunk * 4]) = v;
+      if constexpr (X3) {
+        u32x2 h, m, l;
+        split3(v, h, m, l);
+        char* dst = smem_b + (p * RPP + lrow) * X3_PITCH + chunk * 8;
+        *reinterpret_cast<u32x2*>(dst) = h;
+        *reinterpret_cast<u32x2*>(dst + A_PLANE) = m;
+        *reinterpret_cast<u32x2*>(dst + 2 * A_PLANE) = l;
+      } else {
+        *reinterpret_cast<f32x4*>(&As[(p * RPP + lrow) * LDK + chunk * 4]) = v;
+      }
     }
+    if constexpr (X3) {
 #pragma unroll
-    for (int p = 0; p < PB; ++p)
-      *reinterpret_cast<f32x4*>(&Bs[(p * RPP + lrow) * LDK + chunk * 4]) = rb[p];
+      for (int k = 0; k < PBX; ++k) {
+        const int f = tid + NT * k;
+        const int nl = f / 12, piece = f - nl * 12;
+        const int plane = piece >> 2, j = piece & 3;
+        *reinterpret_cast<u32x4*>(smem_b + B3_BASE + plane * B_PLANE + nl * X3_PITCH + j * 16) = rbx[k];
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < PB; ++p)
+        *reinterpret_cast<f32x4*>(&Bs[(p * RPP + lrow) * LDK + chunk * 4]) = rb[p];
+    }
     __syncthreads();
 
     // ---- prefetch the next K-step while this one is multiplied ------------------------
@@ -195,6 +262,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
     if (ci0 >= a.Cin) { ci0 = 0; ++tapi; }
     if (ks + 1 < k_end) gload(tapi, ci0);
 
+    if constexpr (X3) {
+      // ---- 32 k's = 2 x (16-deep bf16 MFMA) x 6 plane pairs, smallest products first ----------
+      const int fa = arow * X3_PITCH + (lane >> 5) * 16;
+      const int fb = B3_BASE + brow * X3_PITCH + (lane >> 5) * 16;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        bf16x8 af3[3][TM], bf3[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+            af3[pl][tm] = *reinterpret_cast<const bf16x8*>(smem_b + pl * A_PLANE + fa + tm * 32 * X3_PITCH + q * 32);
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            bf3[pl][tn] = *reinterpret_cast<const bf16x8*>(smem_b + pl * B_PLANE + fb + tn * 32 * X3_PITCH + q * 32);
+        }
+        constexpr int PA6[6] = {2, 0, 1, 1, 0, 0};   // A plane: l, h, m, m, h, h
+        constexpr int PB6[6] = {0, 2, 1, 0, 1, 0};   // B plane: h, l, m, h, m, h
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[PA6[c]][tm], bf3[PB6[c]][tn],
+                                                                  acc[tm][tn], 0, 0, 0);
+      }
+    } else {
     // ---- 32 k's = 4 x (float4 fragment -> 4 MFMAs per output sub-tile) -----------------
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -213,6 +308,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_mfma_kernel(const ConvAr
           for (int tn = 0; tn < TN; ++tn)
             acc[tm][tn] =
                 __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][r], bf[tn][r], acc[tm][tn], 0, 0, 0);
+    }
     }
     __syncthreads();
   }
@@ -343,17 +439,17 @@ __global__ void splitk_reduce_kernel(const ReduceArgs r) {
   }
 }
 
-template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC>
+template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3 = false>
 int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int MAIN_FLOATS = (BM + BN) * LDK;
+  constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (BM + BN) * LDK;
   constexpr int EPI_FLOATS = WM * WN * 32 * (TN * 32 + 4);
   const size_t lds = (size_t)(MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS) * sizeof(float) +
                      BM * sizeof(long long);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC, X3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -363,7 +459,7 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
     for (int p = 0; p < a.nphase; ++p) grid += a.tiles_per_phase * a.ntiles_n * a.nsplit[p];
   }
   if (grid <= 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC>), dim3(grid), dim3(NT), lds,
+  hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC, X3>), dim3(grid), dim3(NT), lds,
                      stream, a);
   return (int)hipGetLastError();
 }
@@ -371,6 +467,13 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
 template <int TM, int TN, int WM, int WN>
 int launch_pro(const ConvArgs& a, hipStream_t s) {
   if (a.smallc) return launch_inst<TM, TN, WM, WN, PRO_NONE, true>(a, s);
+  if (a.x3) {
+    switch (a.pro) {
+      case PRO_NONE: return launch_inst<TM, TN, WM, WN, PRO_NONE, false, true>(a, s);
+      case PRO_SQUARE: return launch_inst<TM, TN, WM, WN, PRO_SQUARE, false, true>(a, s);
+      case PRO_IGDN_BWD: return launch_inst<TM, TN, WM, WN, PRO_IGDN_BWD, false, true>(a, s);
+    }
+  }
   switch (a.pro) {
     case PRO_NONE: return launch_inst<TM, TN, WM, WN, PRO_NONE, false>(a, s);
     case PRO_SQUARE: return launch_inst<TM, TN, WM, WN, PRO_SQUARE, false>(a, s);
@@ -403,8 +506,8 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
     case 96: tn = 3; wn = 1; break;
     case 32: tn = 1; tm = 1; wm = 4; wn = 1; break;
   }
-  snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
-           a.smallc ? "true" : "false");
+  snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%s>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
+           a.smallc ? "true" : "false", (a.x3 && !a.smallc && bn != 32) ? "true" : "false");
 }
 
 int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream) {
@@ -429,6 +532,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     case 64: return launch_pro<2, 1, 2, 2>(a, stream);
     case 96:
       if (a.smallc || a.pro != PRO_NONE) return (int)hipErrorInvalidValue;
+      if (a.x3) return launch_inst<2, 3, 2, 1, PRO_NONE, false, true>(a, stream);
       return launch_inst<2, 3, 2, 1, PRO_NONE, false>(a, stream);
     case 32:
       if (a.smallc || a.pro != PRO_NONE) return (int)hipErrorInvalidValue;

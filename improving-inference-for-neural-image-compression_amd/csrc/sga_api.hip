@@ -17,6 +17,7 @@ constexpr int BM_TILE = 128;
 
 struct PackedConv {
   float* w = nullptr;   // device [nslab][Npad][Kc]
+  unsigned short* w3 = nullptr;   // device bf16x3 planes [nslab][Npad][Kc/32][3][32] (precision mode bf16x3)
   int Kc = 0;           // contiguous K per slab row (C_in of the GEMM)
   int N = 0;            // real output channels
   int Npad = 0, bn = 0;
@@ -112,6 +113,7 @@ struct sga_handle {
   struct ProfRec { hipEvent_t a, b; double flops; char name[64]; };
   bool profiling = false;
   bool no_splitk = false;          // SGA_NO_SPLITK=1
+  bool x3 = false;                 // precision mode bf16x3 (sga_config.reserved[0] == 2 or SGA_PRECISION=bf16x3)
   bool profile_by_layer = false;   // SGA_PROFILE_BY_LAYER=1: aggregate by call site instead of symbol
   const char* cur_tag = "";
   std::vector<ProfRec> prof;
@@ -175,6 +177,7 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
 // every MFMA convolution goes through here (so it can be timed)
 int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st) {
   a.ksplit = pick_ksplit(h, a);
+  a.x3 = (h->x3 && a.w3 && !a.smallc && a.epi != EPI_SHUFFLE3) ? 1 : 0;
   const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
   if (a.ksplit > 1) { a.part = h->cur_part->p; a.slab = n_out; }
   sga_handle::ProfRec r;
@@ -232,8 +235,44 @@ int upload(sga_handle* h, float** dst, const float* src, size_t n) {
   return SGA_OK;
 }
 
-int upload_packed(sga_handle* h, PackedConv& pc, const std::vector<float>& host) {
-  return upload(h, &pc.w, host.data(), host.size());
+// round-to-nearest-even f32 -> bf16 (as v_cvt_pk_bf16_f32 does on the device)
+inline unsigned short bf16_rne(float x) {
+  unsigned u;
+  memcpy(&u, &x, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+inline float bf16_to_f32(unsigned short b) {
+  const unsigned u = (unsigned)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+int upload_packed(sga_handle* h, PackedConv& pc, const std::vector<float>& host, bool x3 = true) {
+  SGACHK(upload(h, &pc.w, host.data(), host.size()));
+  if (!x3 || pc.Kc % 32 != 0) return SGA_OK;
+  // bf16x3: w = h + m + l exactly; layout [slab][n][Kc/32][plane][32] so that one K-step of one
+  // output row is 192 contiguous bytes
+  const size_t rows = host.size() / pc.Kc;
+  const int nck = pc.Kc / 32;
+  std::vector<unsigned short> planes(host.size() * 3);
+  for (size_t r = 0; r < rows; ++r)
+    for (int c = 0; c < nck; ++c)
+      for (int k = 0; k < 32; ++k) {
+        const float x = host[r * pc.Kc + c * 32 + k];
+        const unsigned short hi = bf16_rne(x);
+        const float r1 = x - bf16_to_f32(hi);
+        const unsigned short mi = bf16_rne(r1);
+        const unsigned short lo = bf16_rne(r1 - bf16_to_f32(mi));
+        unsigned short* dst = &planes[((r * nck + c) * 3) * 32 + k];
+        dst[0] = hi; dst[32] = mi; dst[64] = lo;
+      }
+  void* p = nullptr;
+  SGACHK(dev_alloc(h, &p, planes.size() * sizeof(unsigned short)));
+  HIPCHK(h, hipMemcpy(p, planes.data(), planes.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  pc.w3 = (unsigned short*)p;
+  return SGA_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -297,7 +336,7 @@ int pack_shuffle3(sga_handle* h, PackedConv& pc, const float* K /*[5][5][C][3]*/
           }
         }
     }
-  return upload_packed(h, pc, w);
+  return upload_packed(h, pc, w, false);
 }
 
 // 5x5/2 conv over a zero-bordered 3-channel image: 3 K-steps of 32 = two kernel rows x 16
@@ -321,7 +360,7 @@ int pack_smallc(sga_handle* h, PackedConv& pc, const float* K, int C, bool bwd) 
         }
       }
     }
-  return upload_packed(h, pc, w);
+  return upload_packed(h, pc, w, false);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -384,6 +423,7 @@ ConvArgs base_args(const PackedConv& pc, int B, int Hg, int Wg) {
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.w = pc.w;
+  a.w3 = pc.w3;
   a.B = B; a.Hg = Hg; a.Wg = Wg;
   a.Cin = pc.Kc; a.Cout = pc.N; a.Npad = pc.Npad;
   a.ntiles_n = pc.Npad / pc.bn;
@@ -856,6 +896,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
       return fail(SGA_ERR_HIP);
   }
+  env = getenv("SGA_PRECISION");
+  h->x3 = cfg->reserved[0] == 2 || (cfg->reserved[0] == 0 && env && strcmp(env, "bf16x3") == 0);
   env = getenv("SGA_NO_SPLITK");
   h->no_splitk = env && env[0] == '1';
   env = getenv("SGA_PROFILE_BY_LAYER");

@@ -65,6 +65,8 @@ struct ConvPhase { int py, px, tap_begin, ntaps; };
 //   output pixel (s_out*i + py, s_out*j + px)
 struct ConvArgs {
   const float* in;  const float* w;  const float* bias;  float* out;
+  // precision mode "bf16x3": weights pre-split into three bf16 planes, [slab][Npad][Cin/32][3][32]
+  const unsigned short* w3;  int x3;
   const float* aux0; const float* aux1; const float* aux2; float* aux_out;
   int in_cs, in_coff;      // channel stride / offset of `in` (and aux1/aux2 in PRO_IGDN_BWD)
   int out_cs, out_coff;    // channel stride / offset of `out` (and aux0/aux_out)
