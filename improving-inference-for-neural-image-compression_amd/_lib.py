@@ -25,7 +25,8 @@ LAYERS = {name: i for i, name in enumerate(
 
 class SgaConfig(C.Structure):
     _fields_ = [("num_filters", C.c_int32), ("max_batch", C.c_int32), ("max_height", C.c_int32),
-                ("max_width", C.c_int32), ("bits_back", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("max_width", C.c_int32), ("bits_back", C.c_int32), ("precision", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 _FP = C.POINTER(C.c_float)
@@ -83,6 +84,7 @@ SYMBOLS["sga_bb_run"] = (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _I, _D, _D, _D, _I
 SYMBOLS["sga_bb_eval"] = (_I, [_P, _P, _I, _I, _I, _P, _P, _P, C.c_uint64, _P, _P])
 SYMBOLS["sga_op_factorized_density"] = (_I, [_P, _P, _I64, _P, _P, _P])
 SYMBOLS["sga_set_relaxation"] = (_I, [_P, _I, _I])
+PRECISIONS = {"default": 0, "f32": 1, "bf16x3": 2}
 RELAXATIONS = {"sga": 0, "danneal": 1, "unoise": 2, "ste": 3, "none": 4}
 SCHEDULES = {"exp0": 0, "exp": 1}
 SYMBOLS["sga_profile_begin"] = (_I, [_P])

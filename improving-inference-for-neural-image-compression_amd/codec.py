@@ -30,7 +30,8 @@ def _ptr(t):
 
 class SGACodec:
     def __init__(self, weights: dict, num_filters: int, max_batch: int, max_height: int,
-                 max_width: int, device: str | torch.device = "cuda:0", bits_back: bool = False):
+                 max_width: int, device: str | torch.device = "cuda:0", bits_back: bool = False,
+                 precision: str = "default"):
         if not torch.cuda.is_available():
             raise RuntimeError("SGACodec needs a ROCm GPU (gfx950); there is no CPU fallback")
         self.lib = _lib.load_library()
@@ -44,7 +45,9 @@ class SGACodec:
         torch.cuda.set_device(self.device)
         # a dedicated non-null stream: hipGraph capture is not allowed on the legacy null stream
         self.stream = torch.cuda.Stream(device=self.device)
-        cfg = _lib.SgaConfig(self.C, self.max_batch, self.max_height, self.max_width, int(bits_back))
+        self.precision = precision
+        cfg = _lib.SgaConfig(self.C, self.max_batch, self.max_height, self.max_width, int(bits_back),
+                             _lib.PRECISIONS[precision])
         w = _lib.SgaWeights()
         keep = []
 

@@ -897,7 +897,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
       return fail(SGA_ERR_HIP);
   }
   env = getenv("SGA_PRECISION");
-  h->x3 = cfg->reserved[0] == 2 || (cfg->reserved[0] == 0 && env && strcmp(env, "bf16x3") == 0);
+  h->x3 = cfg->precision == SGA_PRECISION_BF16X3 ||
+          (cfg->precision == SGA_PRECISION_DEFAULT && env && strcmp(env, "bf16x3") == 0);
   env = getenv("SGA_NO_SPLITK");
   h->no_splitk = env && env[0] == '1';
   env = getenv("SGA_PROFILE_BY_LAYER");

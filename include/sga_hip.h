@@ -54,8 +54,18 @@ typedef struct sga_config {
   int32_t max_height;
   int32_t max_width;
   int32_t bits_back;     /* 0: mbt2018 (sga.py); 1: mbt2018_bb, h_a emits 2C (bb_sga.py:69) */
-  int32_t reserved[3];
+  int32_t precision;     /* sga_precision; 0 = default (SGA_PRECISION env: "f32" | "bf16x3", else f32) */
+  int32_t reserved[2];
 } sga_config;
+
+/* Arithmetic of the convolution contractions.  Both modes take f32 operands and accumulate in f32:
+ *  F32_MFMA : v_mfma_f32_32x32x2_f32, a bitwise f32 fmaf chain.
+ *  BF16X3   : every f32 operand is split EXACTLY into three bf16 values (3 x 8 = 24 mantissa bits);
+ *             the 6 partial products of order >= 2^-16 go through v_mfma_f32_32x32x16_bf16 (each
+ *             bf16 x bf16 product is exact in f32).  Measured error vs f64 is that of an f32 GEMM
+ *             (2.4e-7 vs 4.4e-7 max rel. at K = 4800); the parity suite passes unchanged.  2.67x the
+ *             f32 matrix rate. */
+typedef enum sga_precision { SGA_PRECISION_DEFAULT = 0, SGA_PRECISION_F32_MFMA = 1, SGA_PRECISION_BF16X3 = 2 } sga_precision;
 
 /* Effective (post-reparameterisation) parameters, HOST float32.  Kernels are HWIO
  * (kh,kw,C_in,C_out) as tfc.SignalConv2D stores them; gamma is [C_in(j)][C_out(i)];

@@ -16,13 +16,17 @@ from oracle.sga_oracle import SGAOracle, AdamF32, lower_bound  # noqa: E402
 _CODECS = {}
 
 
-def get_codec(C):
+def get_codec(C, precision="f32"):
     from sga_amd.codec import SGACodec
-    if C not in _CODECS:
+    key = (C, precision)
+    if key not in _CODECS:
         w = sga_amd.make_synthetic_weights(C, seed=0)
-        _CODECS[C] = (SGACodec(w, C, max_batch=4, max_height=96, max_width=96), SGAOracle(w),
-                      SGAOracle(w, dtype=torch.float64), w)
-    return _CODECS[C]
+        _CODECS[key] = (SGACodec(w, C, max_batch=4, max_height=96, max_width=96, precision=precision),
+                        SGAOracle(w), SGAOracle(w, dtype=torch.float64), w)
+    return _CODECS[key]
+
+
+PRECISIONS = ["f32", "bf16x3"]   # v_mfma_f32_32x32x2_f32 chain / exact 3 x bf16 operand split, same tolerances
 
 
 def rel_err(a, b):
@@ -58,26 +62,28 @@ def _layer_input(layer, C, B=2, seed=0):
     return rng.standard_normal((B, Hi, Wi, cin)).astype(np.float32)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("C", [64, 128, 192])
 @pytest.mark.parametrize("layer", list(LAYER_IN))
-def test_layer_forward(layer, C, gpu_out_dir):
+def test_layer_forward(layer, C, precision, gpu_out_dir):
     """conv / transposed conv / 3x3 conv (+ GDN, IGDN, ReLU) vs torch.nn.functional on
     asymmetric random kernels and odd sizes (catches flip / transposition / padding errors)."""
-    codec, orc, _, _ = get_codec(C)
+    codec, orc, _, _ = get_codec(C, precision)
     x = _layer_input(layer, C)
     want = orc.layer_fwd(layer, x).numpy()
     got = codec.layer_fwd(layer, x).cpu().numpy()
     assert got.shape == want.shape
     e = rel_err(got, want)
-    report(gpu_out_dir, "layer_fwd", layer=layer, C=C, rel_err=e)
+    report(gpu_out_dir, "layer_fwd", layer=layer, C=C, precision=precision, rel_err=e)
     assert e < 2e-5, f"{layer} C={C}: {where_bad(got, want, 2e-5)}"
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("C", [64, 192])
 @pytest.mark.parametrize("layer", ["GS0", "GS1", "GS2", "GS3", "HS0", "HS1", "HS2"])
-def test_layer_backward(layer, C, gpu_out_dir):
+def test_layer_backward(layer, C, precision, gpu_out_dir):
     """data-gradient of each synthesis-side layer vs float64 autograd of the oracle."""
-    codec, orc, orc64, _ = get_codec(C)
+    codec, orc, orc64, _ = get_codec(C, precision)
     x = _layer_input(layer, C, seed=3)
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     out = orc64.layer_fwd(layer, xt)
@@ -85,7 +91,7 @@ def test_layer_backward(layer, C, gpu_out_dir):
     (want,) = torch.autograd.grad(out, xt, torch.tensor(g_out, dtype=torch.float64))
     got = codec.layer_bwd(layer, x, g_out).cpu().numpy()
     e = rel_err(got, want.numpy())
-    report(gpu_out_dir, "layer_bwd", layer=layer, C=C, rel_err=e)
+    report(gpu_out_dir, "layer_bwd", layer=layer, C=C, precision=precision, rel_err=e)
     assert e < 5e-5, f"{layer} C={C}: {where_bad(got, want.numpy(), 5e-5)}"
 
 

@@ -18,13 +18,17 @@ from oracle.sga_oracle import SGAOracle  # noqa: E402
 _CACHE = {}
 
 
-def setup(C, B, H, W):
+def setup(C, B, H, W, precision="f32"):
     from sga_amd.codec import SGACodec
-    key = (C, B, H, W)
+    key = (C, B, H, W, precision)
     if key not in _CACHE:
         w = sga_amd.make_synthetic_weights(C, seed=0)
-        _CACHE[key] = (SGACodec(w, C, B, H, W), SGAOracle(w), SGAOracle(w, dtype=torch.float64))
+        _CACHE[key] = (SGACodec(w, C, B, H, W, precision=precision), SGAOracle(w),
+                       SGAOracle(w, dtype=torch.float64))
     return _CACHE[key]
+
+
+PRECISIONS = ["f32", "bf16x3"]
 
 
 def rel_err(a, b):
@@ -57,12 +61,13 @@ def test_encode(C, B, H, W, gpu_out_dir):
     assert ey < 5e-5 and ez < 1e-4
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("T", [0.5, 0.15])
 @pytest.mark.parametrize("C,B,H,W", SHAPES)
-def test_step_grads_injected_noise(C, B, H, W, T, gpu_out_dir):
+def test_step_grads_injected_noise(C, B, H, W, T, precision, gpu_out_dir):
     """Full-step gradient vs float64 autograd of the oracle (rel err <= 1e-4 of the max
     gradient) and the logged scalars (sga.py:212)."""
-    codec, orc, orc64 = setup(C, B, H, W)
+    codec, orc, orc64 = setup(C, B, H, W, precision)
     x = image(B, H, W, seed=1)
     yo, zo = orc.encode(x)
     rng = np.random.RandomState(9)
@@ -76,7 +81,7 @@ def test_step_grads_injected_noise(C, B, H, W, T, gpu_out_dir):
     got = codec.step_grads(x, y0, z0, T, lam, u_y=u_y, u_z=u_z)
     ey = rel_err(got["gy"].cpu().numpy(), ref["gy"].numpy())
     ez = rel_err(got["gz"].cpu().numpy(), ref["gz"].numpy())
-    report(gpu_out_dir, "step_grads", C=C, B=B, H=H, W=W, T=T, rel_err_gy=ey, rel_err_gz=ez,
+    report(gpu_out_dir, "step_grads", C=C, B=B, H=H, W=W, T=T, precision=precision, rel_err_gy=ey, rel_err_gz=ez,
            rd_loss=got["rd_loss"], rd_loss_ref=ref["rd_loss"])
     assert ey < 1e-4, f"gy rel err {ey}"
     assert ez < 1e-4, f"gz rel err {ez}"
@@ -150,15 +155,16 @@ def test_base_compress(gpu_out_dir):
     assert np.allclose(got["psnr"], want["psnr"], atol=0.02)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("graph", [True, False])
-def test_run_short_vs_oracle(graph, gpu_out_dir, monkeypatch):
+def test_run_short_vs_oracle(graph, precision, gpu_out_dir, monkeypatch):
     """40 fused iterations (Philox noise, on-device Adam, hipGraph replay or eager launches)
     vs the oracle loop: latents stay within float32 drift, per-step trace agrees."""
     from sga_amd.codec import SGACodec, metrics_to_dict
     C, B, H, W = 64, 2, 64, 64
     w = sga_amd.make_synthetic_weights(C, seed=0)
     monkeypatch.setenv("SGA_NO_GRAPH", "0" if graph else "1")
-    codec = SGACodec(w, C, B, H, W)
+    codec = SGACodec(w, C, B, H, W, precision=precision)
     orc = SGAOracle(w)
     x = image(B, H, W, seed=6)
     its = 40
@@ -166,7 +172,7 @@ def test_run_short_vs_oracle(graph, gpu_out_dir, monkeypatch):
     y_hat, z_hat, met, tr = codec.run(x, 0.01, its=its, t0=10, annealing_rate=0.02, seed=11, trace=True)
     yo, zo, mo, tro = orc.run(x, 0.01, its=its, t0=10, r=0.02, seed=11, trace=True)
     tr = tr.cpu().numpy()
-    report(gpu_out_dir, "run_short", graph=graph, trace_gpu_last=tr[-1].tolist(), trace_ref_last=tro[-1].tolist(),
+    report(gpu_out_dir, "run_short", graph=graph, precision=precision, trace_gpu_last=tr[-1].tolist(), trace_ref_last=tro[-1].tolist(),
            max_trace_rel=float(np.abs(tr / tro - 1).max()))
     assert np.allclose(tr[:, :3], tro[:, :3], rtol=2e-3), np.abs(tr / tro - 1).max(0)
     frac_diff = float((y_hat.cpu().numpy() != yo).mean())
