@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")   # see sga_amd/__init__.py; must precede HIP init
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -90,6 +91,11 @@ def main():
     ap.add_argument("--num_filters", type=int, default=192)
     ap.add_argument("--its", type=int, default=2000)
     ap.add_argument("--lmbda", type=float, default=0.01)
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+                    help="arithmetic of the conv contractions for the HEADLINE value: f32 = "
+                         "v_mfma_f32_32x32x2_f32 (default); bf16x3 = exact 3 x bf16 operand split")
+    ap.add_argument("--no-alt-precision", action="store_true",
+                    help="skip the secondary measurement in the other precision mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
@@ -121,12 +127,12 @@ def main():
     from sga_amd.codec import SGACodec
     B, H, W, C = args.batch, args.size, args.size, args.num_filters
     weights = sga_amd.make_synthetic_weights(C, seed=0)
-    codec = SGACodec(weights, C, B, H, W, device=device)
+    codec = SGACodec(weights, C, B, H, W, device=device, precision=args.precision)
     gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
     x = torch.rand(B, H, W, 3, generator=gen).to(device)     # resident in HBM before timing
 
-    def one_step(seed):
-        y_hat, z_hat, met, _ = codec.run(x, args.lmbda, its=args.its, seed=seed)
+    def one_step(seed, cdc=None):
+        y_hat, z_hat, met, _ = (cdc or codec).run(x, args.lmbda, its=args.its, seed=seed)
         if dist is not None:     # result gather: the only collective on this path (RCCL)
             src = met if backend == "nccl" else met.cpu()
             out = [torch.empty_like(src) for _ in range(world)]
@@ -172,6 +178,44 @@ def main():
                             avg_launch_us=round(1e3 * k["ms_total"] / k["launches"], 2),
                             gflop_per_launch=round(k["flops_total"] / k["launches"] / 1e9, 4),
                             launches=k["launches"], traffic=None)
+    # ---- HBM traffic of the dominant kernel from the committed PMC profile (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 on gfx950; scripts/pmc_traffic.py) ------
+    if roofline is not None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                tr = json.load(f)
+            ent = tr.get(roofline["kernel"])
+            if ent:
+                roofline["traffic"] = ent["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = tr.get("_source")
+        except (OSError, ValueError):
+            pass
+
+    # ---- secondary measurement: the other precision mode, same workload ---------------------------
+    alt = None
+    if rank == 0 and world == 1 and not args.no_alt_precision:
+        other = "bf16x3" if args.precision == "f32" else "f32"
+        codec2 = SGACodec(weights, C, B, H, W, device=device, precision=other)
+        one_step(0, codec2)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            met2 = one_step(100 + i, codec2)
+        torch.cuda.synchronize(device)
+        el2 = time.perf_counter() - t1
+        alt = dict(precision=other, value=round(B * args.steps / el2, 4),
+                   ms_per_step=round(1e3 * el2 / args.steps, 2),
+                   final_est_bpp_mean=float(met2[:, 4].mean()), final_psnr_mean=float(met2[:, 1].mean()))
+        if not args.no_kernel_profile:
+            codec2.profile_begin()
+            codec2.run(x, args.lmbda, its=min(args.its, 60), seed=7, metrics=False)
+            k2 = sorted(codec2.profile_end(), key=lambda k: -k["ms_total"])
+            if k2:
+                a2 = k2[0]["flops_total"] / (k2[0]["ms_total"] * 1e-3) / 1e12
+                alt["dominant_kernel"] = dict(name=k2[0]["name"], algorithmic_tflops=round(a2, 2),
+                                              avg_launch_us=round(1e3 * k2[0]["ms_total"] / k2[0]["launches"], 2))
+        codec2.close()
+
     tf_per_image = gflop_per_image_step(H, W, C) * args.its / 1e3
     path_frac = value / world * tf_per_image / FP32_MFMA_PEAK_TFLOPS
 
@@ -185,15 +229,17 @@ def main():
             "metric": "images/sec for 2000-step SGA (num_filters=192, 256x256) + final BPP/PSNR match",
             "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (3 x bf16 exact operand split, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"sga.py {args.its}-step SGA, num_filters={C}, lambda={args.lmbda}, "
                                    f"batch of {B} synthetic {H}x{W} images per GPU",
                        "images_per_step": world * B, "sga_iterations": args.its,
                        "weights": "synthetic (make_synthetic_weights seed 0)",
                        "parallelism": f"images sharded over {world} GPU(s), RCCL all_gather of metrics"},
+            "precision": args.precision,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "alt_precision": alt,
             "path_frac_of_fp32_mfma_peak": round(path_frac, 4),
             "tflop_per_image": round(tf_per_image, 3),
             "final_est_bpp_mean": float(np.mean(m[:, 4])), "final_psnr_mean": float(np.mean(m[:, 1])),
