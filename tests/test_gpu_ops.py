@@ -197,6 +197,20 @@ def test_gaussian_likelihood(gpu_out_dir):
     assert abs(float(tot.sum()) - 1.0) < 1e-4
 
 
+def test_gaussian_likelihood_reference_fixture():
+    """sga_op_gaussian_likelihood vs the outputs of the reference's own
+    utils.box_convolved_gaussian_pdf (tests/golden/utils_reference.npz; float64 there, f32 here)."""
+    codec, *_ = get_codec(64)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "utils_reference.npz"))
+    ok = g["box_sigma"] >= 0.11                 # below: the op applies the scale bound of sga.py:129
+    y, mu, sigma, want = (g[k][ok] for k in ("box_y", "box_mu", "box_sigma", "box_out"))
+    p, *_ = codec.gaussian_likelihood(y.astype(np.float32), mu.astype(np.float32),
+                                      np.log(sigma).astype(np.float32))
+    p = p.cpu().numpy().astype(np.float64)
+    # inputs rounded to f32 move p by up to ~|dp/dy| * 2^-24 |y|: compare with a mixed tolerance
+    assert np.allclose(p, want, rtol=2e-4, atol=1e-7), float(np.abs(p - want).max())
+
+
 def test_lower_bound_truth_table():
     """math_ops.py:63-76 (oracle side; the kernels' use of it is covered by step parity)."""
     x = torch.tensor([0.5, 0.5, 2.0, 2.0], requires_grad=True)

@@ -88,6 +88,35 @@ def test_eval_batch_size_fixture():
         assert host_fn(int(px)) == want
 
 
+def test_utils_fixtures_from_reference():
+    """tests/golden/utils_reference.npz + runnames.json: outputs of the reference's own utils.py
+    functions (scripts/make_golden_from_reference.py) vs the oracle's and the host driver's
+    restatements."""
+    from sga_amd import driver
+    g = np.load(os.path.join(GOLDEN, "utils_reference.npz"))
+    its = range(2000)
+    for key, kw in (("T_exp0_r1e-3_ub0.5_t0700", dict(r=1e-3, ub=0.5, scheme="exp0", t0=700)),
+                    ("T_exp0_r2e-3_ub0.5_t0100", dict(r=2e-3, ub=0.5, scheme="exp0", t0=100)),
+                    ("T_exp_r1e-3_ub1.0", dict(r=1e-3, ub=1.0, scheme="exp"))):
+        for fn in (annealed_temperature, driver.annealed_temperature):
+            mine = np.array([fn(t, **kw) for t in its], np.float64)
+            assert np.allclose(mine, g[key], rtol=1e-15, atol=0), (key, fn.__module__)
+    # ln N(sample; mean, exp(logvar)) in float32 (utils.py:75-77; bb_sga.py:106)
+    mine = SGAOracle.log_normal_pdf(*(torch.tensor(g[k]) for k in ("lnpdf_sample", "lnpdf_mean", "lnpdf_logvar")))
+    assert mine.dtype == torch.float32
+    assert np.allclose(mine.numpy(), g["lnpdf_out"], rtol=2e-6, atol=2e-6)
+    # box-convolved Gaussian (utils.py:86-102); the oracle adds the 0.11 scale bound of sga.py:129
+    y, mu, sigma = (torch.tensor(g[k], dtype=torch.float64) for k in ("box_y", "box_mu", "box_sigma"))
+    mine = SGAOracle.gauss_likelihood(y, mu, sigma).numpy()
+    ok = g["box_sigma"] >= 0.11
+    assert ok.sum() >= 350
+    assert np.allclose(mine[ok], g["box_out"][ok], rtol=1e-9, atol=1e-300)
+    # run names (utils.py:51-69) -> lambda (sga.py:158)
+    with open(os.path.join(GOLDEN, "runnames.json")) as f:
+        for case in json.load(f):
+            assert driver.lambda_from_runname(case["runname"]) == case["args"]["lmbda"]
+
+
 def test_temperature_schedule():
     """utils.py:166-180 'exp0': T(0)=T(700)=0.5, T(1999)=0.5*exp(-1.299)."""
     assert annealed_temperature(0) == 0.5
