@@ -541,6 +541,33 @@ __global__ void k_advance_ctx(StepCtx* ctx, const float* __restrict__ Ttab,
   ctx->lr_t = lrtab[it];
 }
 
+// debug (SGA_DEBUG_FORK=1): is the side stream really behind the main stream's k_advance_ctx?
+__global__ void k_check_iter(const StepCtx* __restrict__ ctx, int expected_it, int* __restrict__ bad) {
+  if (ctx->it != expected_it) atomicAdd(bad, 1);
+}
+
+// One-wave kernel placed on either side of a cross-stream event (see rd_forward_backward).
+__global__ void k_fence() { __threadfence_system(); }
+
+// debug (SGA_DEBUG_DUMP): order-independent 64-bit checksum of a float buffer
+__global__ void k_checksum(const unsigned* __restrict__ p, int64_t n, unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    acc += (unsigned long long)p[i] * (2654435761ull * (unsigned long long)(i + 1) + 0x9E3779B97F4A7C15ull);
+  atomicAdd(out, acc);
+}
+
+// debug: hold a stream for `ticks` of the 100 MHz wall clock (SGA_DEBUG_DELAY_US)
+__global__ void k_spin(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+__global__ void k_set_int(int* p, int v) { *p = v; }
+__global__ void k_check_int(const int* __restrict__ p, int expected, int* __restrict__ bad) {
+  if (*p != expected) atomicAdd(bad, 1);
+}
+
 __global__ void k_finalize_step(ImgSums* sums, const StepCtx* __restrict__ ctx, int B, int H,
                                 int W, float* scalars, float* psnr, float* trace) {
   if (threadIdx.x != 0) return;
@@ -643,6 +670,13 @@ __global__ void k_fill(float* __restrict__ p, float val, int64_t n) {
     p[i] = val;
 }
 
+// device-to-device copy as a kernel on the caller's stream (see launch_copy)
+__global__ void k_copy(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
 __global__ void k_relu_mask(const float* __restrict__ g, const float* __restrict__ act,
                             float* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -741,6 +775,32 @@ int launch_advance_ctx(StepCtx* ctx, const float* Ttab, const float* lrtab, hipS
   LAUNCH_RET();
 }
 
+int launch_check_iter(const StepCtx* ctx, int expected_it, int* bad, hipStream_t s) {
+  hipLaunchKernelGGL(k_check_iter, dim3(1), dim3(1), 0, s, ctx, expected_it, bad);
+  LAUNCH_RET();
+}
+
+int launch_fence(hipStream_t s) {
+  hipLaunchKernelGGL(k_fence, dim3(64), dim3(64), 0, s);   // >= 1 workgroup per XCD (8 XCDs, round-robin)
+  LAUNCH_RET();
+}
+int launch_checksum(const float* p, int64_t n, unsigned long long* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_checksum, dim3(grid_for(n, 256, 256)), dim3(256), 0, s, (const unsigned*)p, n, out);
+  LAUNCH_RET();
+}
+int launch_spin(int us, hipStream_t s) {
+  hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, (long long)us * 100);
+  LAUNCH_RET();
+}
+int launch_set_int(int* p, int v, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, p, v);
+  LAUNCH_RET();
+}
+int launch_check_int(const int* p, int expected, int* bad, hipStream_t s) {
+  hipLaunchKernelGGL(k_check_int, dim3(1), dim3(1), 0, s, p, expected, bad);
+  LAUNCH_RET();
+}
+
 int launch_finalize_step(ImgSums* sums, const StepCtx* ctx, int B, int H, int W, float* scalars,
                          float* psnr, float* trace, hipStream_t s) {
   hipLaunchKernelGGL(k_finalize_step, dim3(1), dim3(64), 0, s, sums, ctx, B, H, W, scalars, psnr,
@@ -773,6 +833,14 @@ int launch_round_median(const float* z, const float* med, int64_t n, int C, floa
 
 int launch_fill(float* p, float val, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(256), 0, s, p, val, n);
+  LAUNCH_RET();
+}
+
+// Copies and clears inside the step sequences are kernels on the caller's compute queue rather
+// than hipMemcpyAsync/hipMemsetAsync (which the runtime may route to a copy engine or a blit
+// kernel of its own): one ordering domain, and capturable into the step graph as plain kernel nodes.
+int launch_copy(float* dst, const float* src, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy, dim3(grid_for(n)), dim3(256), 0, s, dst, src, n);
   LAUNCH_RET();
 }
 

@@ -73,6 +73,13 @@ int launch_round_centered(const float* y, const float* ms, int B, int h, int w, 
 int launch_round_median(const float* z, const float* med, int64_t n, int C, float* out,
                         hipStream_t s);
 int launch_fill(float* p, float val, int64_t n, hipStream_t s);
+int launch_check_iter(const StepCtx* ctx, int expected_it, int* bad, hipStream_t s);
+int launch_fence(hipStream_t s);
+int launch_checksum(const float* p, int64_t n, unsigned long long* out, hipStream_t s);
+int launch_spin(int us, hipStream_t s);
+int launch_set_int(int* p, int v, hipStream_t s);
+int launch_check_int(const int* p, int expected, int* bad, hipStream_t s);
+int launch_copy(float* dst, const float* src, int64_t n, hipStream_t s);
 
 // ---- bits-back variant (bb_sga.py) -------------------------------------------------------------
 // z_tilde = eps*exp(.5 logvar) + mean with (mean | logvar) = zml [B,npix,2C] (bb_sga.py:99-100);

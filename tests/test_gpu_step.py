@@ -183,16 +183,25 @@ def test_run_short_vs_oracle(graph, precision, gpu_out_dir, monkeypatch):
     codec.close()
 
 
-def test_run_deterministic(gpu_out_dir):
-    """Same seed -> bit-identical rounded latents (no atomics on the gradient path)."""
+@pytest.mark.parametrize("graph", [True, False])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_run_deterministic(precision, graph, gpu_out_dir, monkeypatch):
+    """Same seed -> bit-identical rounded latents AND metrics, hipGraph replay or eager two-stream
+    launches, both precision modes (no atomics on the gradient path; the f64 sums feeding the
+    metrics are per-image and added in a fixed block order only up to atomics: rtol 1e-6)."""
+    from sga_amd.codec import SGACodec
     C, B, H, W = 64, 2, 64, 64
-    codec, _, _ = setup(C, B, H, W)
+    monkeypatch.setenv("SGA_NO_GRAPH", "0" if graph else "1")
+    codec = SGACodec(sga_amd.make_synthetic_weights(C, seed=0), C, B, H, W, precision=precision)
     x = image(B, H, W, seed=7)
-    a = codec.run(x, 0.01, its=25, seed=3)
-    b = codec.run(x, 0.01, its=25, seed=3)
-    c = codec.run(x, 0.01, its=25, seed=4)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    a = codec.run(x, 0.01, its=60, seed=3)
+    for _ in range(4):
+        b = codec.run(x, 0.01, its=60, seed=3)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert torch.allclose(a[2], b[2], rtol=1e-6, atol=0, equal_nan=True)
+    c = codec.run(x, 0.01, its=60, seed=4)
     assert not torch.equal(a[0], c[0])
+    codec.close()
 
 
 def test_eval_msssim(gpu_out_dir):
