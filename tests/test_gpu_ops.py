@@ -63,7 +63,7 @@ def _layer_input(layer, C, B=2, seed=0):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("C", [64, 128, 192])
+@pytest.mark.parametrize("C", [64, 128, 192, 256])
 @pytest.mark.parametrize("layer", list(LAYER_IN))
 def test_layer_forward(layer, C, precision, gpu_out_dir):
     """conv / transposed conv / 3x3 conv (+ GDN, IGDN, ReLU) vs torch.nn.functional on
@@ -79,7 +79,7 @@ def test_layer_forward(layer, C, precision, gpu_out_dir):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("C", [64, 192])
+@pytest.mark.parametrize("C", [64, 192, 256])
 @pytest.mark.parametrize("layer", ["GS0", "GS1", "GS2", "GS3", "HS0", "HS1", "HS2"])
 def test_layer_backward(layer, C, precision, gpu_out_dir):
     """data-gradient of each synthesis-side layer vs float64 autograd of the oracle."""
