@@ -60,6 +60,10 @@ SYMBOLS = {
     "sga_adam": (_I, [_P, _P, _P, _P, _P, _I64, _I, _D, _D, _D, _D, _P]),
     "sga_run": (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _D, _D, _I, _D, C.c_uint64,
                      _P, _P, _P, _P, _P, _P, _P]),
+    "sga_run_begin": (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _D, _D, _I, _D, C.c_uint64, _P, _P, _P]),
+    "sga_run_steps": (_I, [_P, _I, _P]),
+    "sga_run_state": (_I, [_P, _I, _P, _P, _P, _P]),
+    "sga_quantize_centered": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "sga_eval": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "sga_base_compress": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "sga_op_layer_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),

@@ -183,6 +183,57 @@ class SGACodec:
         self._exit()
         return y_hat, z_hat, met, (tr[:its] if trace else None)
 
+    # ---- the same loop in pieces (map.py / ste.py decide on the host every 10 iterations) ------
+    def run_begin(self, x, lmbda, its=2000, lr=0.005, annealing_rate=1e-3, t0=700, T_ub=0.5, seed=0,
+                  loss_scale=None, y0=None, z0=None):
+        x = self._t(x)
+        B, H, W, ys, zs = self._shapes(x)
+        if loss_scale is None:
+            loss_scale = 1.0 / B
+        y0t = self._t(y0, ys) if y0 is not None else None
+        z0t = self._t(z0, zs) if z0 is not None else None
+        self._run = (x, B, H, W, ys, zs, int(its))
+        s = self._enter()
+        self._chk(self.lib.sga_run_begin(self.handle, _ptr(x), B, H, W, float(lmbda), float(loss_scale),
+                                         int(its), float(lr), float(annealing_rate), int(t0), float(T_ub),
+                                         int(seed), _ptr(y0t), _ptr(z0t), s), "sga_run_begin")
+        self._exit()
+
+    def run_steps(self, n):
+        s = self._enter()
+        self._chk(self.lib.sga_run_steps(self.handle, int(n), s), "sga_run_steps")
+        self._exit()
+
+    def run_latents(self, trace=False):
+        """Current continuous (y, z) [and the trace of the iterations done so far]."""
+        _, B, H, W, ys, zs, its = self._run
+        y, z = self._empty(*ys), self._empty(*zs)
+        tr = self._empty(max(its, 1), 4) if trace else None
+        s = self._enter()
+        self._chk(self.lib.sga_run_state(self.handle, 0, _ptr(y), _ptr(z), _ptr(tr), s), "sga_run_state")
+        self._exit()
+        return (y, z, tr) if trace else (y, z)
+
+    def run_set_latents(self, y, z):
+        _, B, H, W, ys, zs, its = self._run
+        y, z = self._t(y, ys), self._t(z, zs)
+        s = self._enter()
+        self._chk(self.lib.sga_run_state(self.handle, 1, _ptr(y), _ptr(z), None, s), "sga_run_state")
+        self._exit()
+
+    def quantize_centered(self, y, z, H, W, medians=None):
+        """tfc `_quantize(., 'dequantize')`: z_hat = round(z - median) + median, y_hat = round(y - mu)
+        + mu with mu = h_s(z)[..., :C] (map.py:83,101)."""
+        y, z = self._t(y), self._t(z)
+        B = y.shape[0]
+        med = self._t(medians, (self.C,)) if medians is not None else None
+        y_hat, z_hat = torch.empty_like(y), torch.empty_like(z)
+        s = self._enter()
+        self._chk(self.lib.sga_quantize_centered(self.handle, _ptr(y), _ptr(z), B, int(H), int(W), _ptr(med),
+                                                 _ptr(y_hat), _ptr(z_hat), s), "sga_quantize_centered")
+        self._exit()
+        return y_hat, z_hat
+
     def evaluate(self, x, y_hat, z_hat, want_x_hat=False):
         x = self._t(x)
         B, H, W, ys, zs = self._shapes(x)

@@ -97,6 +97,8 @@ struct sga_handle {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;           // eager launches
   const char* dump_path = nullptr; unsigned long long* dump = nullptr; int dump_run = 0;   // SGA_DEBUG_DUMP
   char x3_skip[128] = {0};         // SGA_X3_SKIP="gs0.fwd,gs1.bwd" (experiments)
+  int run_B = 0, run_H = 0, run_W = 0, run_its = -1, run_it = 0;   // sga_run_begin/steps state
+  float run_lambda = 0.f, run_loss_scale = 1.f; uint64_t run_seed = 0;
   int x3_mask = 3;                 // SGA_X3_MASK
   int dbg_delay_us = 0;            // SGA_DEBUG_DELAY_US: stall the side branch (experiments)
   bool fences = true;              // SGA_NO_FENCES=1 removes the one-wave kernels around fork/join
@@ -1077,16 +1079,17 @@ int sga_eval(sga_handle* h, const float* x, int B, int H, int W, const float* y_
   return eval_impl(h, g, x, y_hat, z_hat, metrics, x_hat, st);
 }
 
-int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, float loss_scale,
-            int its, double lr, double annealing_rate, int t0, double T_ub, uint64_t seed,
-            const float* y0, const float* z0, float* y_hat, float* z_hat, float* metrics,
-            float* trace, void* stream) {
+// ---- the per-batch loop in three pieces (sga_run = begin + steps(its) + round/eval) -----------
+int sga_run_begin(sga_handle* h, const float* x, int B, int H, int W, float lambda, float loss_scale,
+                  int its, double lr, double annealing_rate, int t0, double T_ub, uint64_t seed,
+                  const float* y0, const float* z0, void* stream) {
   if (!h || !x || its < 0 || its > kMaxIts || (y0 == nullptr) != (z0 == nullptr)) return SGA_ERR_BAD_ARG;
   SGACHK(check_shape(h, B, H, W));
   hipStream_t st = (hipStream_t)stream;
   const Geom g = make_geom(B, H, W);
   const int C = h->C;
   const int64_t ny = (int64_t)B * g.yh * g.yw * C, nz = (int64_t)B * g.zh * g.zw * C;
+  h->run_its = -1;
   SGACHK(ensure_borders(h, g, st));
   // x is kept in handle-owned memory so the captured graph does not depend on caller pointers
   HIPCHK(h, launch_copy(h->xin.p, x, (int64_t)((size_t)B * H * W * 3), st));
@@ -1101,8 +1104,6 @@ int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, fl
   HIPCHK(h, launch_fill(h->vy.p, 0.f, (int64_t)(ny), st));
   HIPCHK(h, launch_fill(h->mz.p, 0.f, (int64_t)(nz), st));
   HIPCHK(h, launch_fill(h->vz.p, 0.f, (int64_t)(nz), st));
-  HIPCHK(h, launch_fill((float*)h->sums, 0.f, (int64_t)(sizeof(ImgSums) / sizeof(float)) * (B), st));
-
   if (its > 0) {
     // host tables: utils.py:166-180 ('exp0') and adam.py:40-42, evaluated in double
     h->hT.resize(its); h->hLr.resize(its);
@@ -1118,79 +1119,144 @@ int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, fl
     HIPCHK(h, hipMemcpyAsync(h->Ttab.p, h->hT.data(), its * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(h->lrtab.p, h->hLr.data(), its * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(h, hipStreamSynchronize(st));   // host vectors may now be reused
-    HIPCHK(h, launch_set_ctx(h->ctx, -1, its, 0.f, 0.f, lambda, loss_scale, seed, st));
-
     if (h->dump) (void)hipMemsetAsync(h->dump, 0, (size_t)its * 16 * 8, st);
-    auto enqueue_step = [&](hipStream_t s) -> int {
-      HIPCHK(h, launch_advance_ctx(h->ctx, h->Ttab.p, h->lrtab.p, s));
-      SGACHK(sga_step_core(h, g, h->xin.p, h->y.p, h->z.p, nullptr, nullptr, s));
-      HIPCHK(h, launch_adam_latent(h->y.p, h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, h->my.p, h->vy.p, ny, h->ctx, s));
-      HIPCHK(h, launch_adam_latent(h->z.p, h->g_zt_hs.p, h->g_zt_eb.p, h->dzt.p, h->mz.p, h->vz.p, nz, h->ctx, s));
-      HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, nullptr, nullptr, h->trace.p, s));
-      if (h->dump && h->dbg_it >= 0) {
-        unsigned long long* o = h->dump + (size_t)h->dbg_it * 16;
-        const float* bufs[12] = {h->yt.p, h->zt.p, h->u[0].p, h->v[0].p, h->u[1].p, h->u[2].p, h->g_yt_dist.p,
-                                 h->g_yt_rate.p, h->g_zt_hs.p, h->g_zt_eb.p, h->y.p, h->z.p};
-        const int64_t ns[12] = {ny, nz, ny * 4, ny * 4, ny * 16, ny * 64, ny, ny, nz, nz, ny, nz};
-        for (int k = 0; k < 12; ++k) HIPCHK(h, launch_checksum(bufs[k], ns[k], o + k, s));
-      }
-      return SGA_OK;
-    };
-
-    bool graphed = false;
-    if (h->use_graph && !h->profiling) {
-      if (!h->graph_exec || h->graph_B != B || h->graph_H != H || h->graph_W != W ||
-          h->graph_relax != h->relax) {
-        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-        hipGraph_t graph = nullptr;
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-          const int rc = enqueue_step(st);
-          const hipError_t ec = hipStreamEndCapture(st, &graph);
-          if (rc == SGA_OK && ec == hipSuccess && graph &&
-              hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-            h->graph_B = B; h->graph_H = H; h->graph_W = W; h->graph_relax = h->relax;
-          } else {
-            h->graph_exec = nullptr;
-          }
-          if (graph) (void)hipGraphDestroy(graph);
-        }
-        (void)hipGetLastError();
-      }
-      graphed = h->graph_exec != nullptr;
-    }
-    for (int it = 0; it < its; ++it) {
-      h->dbg_it = it;
-      if (graphed) HIPCHK(h, hipGraphLaunch(h->graph_exec, st));
-      else SGACHK(enqueue_step(st));
-    }
-    h->dbg_it = -1;
-    if (h->dump) {
-      std::vector<unsigned long long> host((size_t)its * 16);
-      (void)hipDeviceSynchronize();
-      (void)hipMemcpy(host.data(), h->dump, host.size() * 8, hipMemcpyDeviceToHost);
-      char fn[512];
-      snprintf(fn, sizeof(fn), "%s.%d", h->dump_path, h->dump_run++);
-      if (FILE* f = fopen(fn, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
-    }
-    if (h->dbg_fork) {
-      int bad = -1;
-      (void)hipDeviceSynchronize();
-      (void)hipMemcpy(&bad, h->dbg_bad, sizeof(int), hipMemcpyDeviceToHost);
-      int badj = -1;
-      (void)hipMemcpy(&badj, h->dbg_bad + 1, sizeof(int), hipMemcpyDeviceToHost);
-      fprintf(stderr, "[sga debug] of %d iterations: side stream ahead of the fork %d, main stream ahead of the join %d\n",
-              its, bad, badj);
-      (void)hipMemset(h->dbg_bad, 0, 2 * sizeof(int));
-    }
-    if (trace)
-      HIPCHK(h, launch_copy(trace, h->trace.p, (int64_t)((size_t)its * 4), st));
   }
+  h->run_B = B; h->run_H = H; h->run_W = W; h->run_its = its; h->run_it = 0;
+  h->run_lambda = lambda; h->run_loss_scale = loss_scale; h->run_seed = seed;
+  return SGA_OK;
+}
+
+int sga_run_steps(sga_handle* h, int n, void* stream) {
+  if (!h || n < 0 || h->run_its < 0) return SGA_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = h->run_B, H = h->run_H, W = h->run_W, its = h->run_its;
+  if (n > its - h->run_it) n = its - h->run_it;
+  if (n == 0) return SGA_OK;
+  const Geom g = make_geom(B, H, W);
+  const int C = h->C;
+  const int64_t ny = (int64_t)B * g.yh * g.yw * C, nz = (int64_t)B * g.zh * g.zw * C;
+  // other entry points (sga_step_grads, sga_eval) may have used the step context and the sums
+  HIPCHK(h, launch_set_ctx(h->ctx, h->run_it - 1, its, 0.f, 0.f, h->run_lambda, h->run_loss_scale, h->run_seed, st));
+  HIPCHK(h, launch_fill((float*)h->sums, 0.f, (int64_t)(sizeof(ImgSums) / sizeof(float)) * (B), st));
+
+  auto enqueue_step = [&](hipStream_t s) -> int {
+    HIPCHK(h, launch_advance_ctx(h->ctx, h->Ttab.p, h->lrtab.p, s));
+    SGACHK(sga_step_core(h, g, h->xin.p, h->y.p, h->z.p, nullptr, nullptr, s));
+    HIPCHK(h, launch_adam_latent(h->y.p, h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, h->my.p, h->vy.p, ny, h->ctx, s));
+    HIPCHK(h, launch_adam_latent(h->z.p, h->g_zt_hs.p, h->g_zt_eb.p, h->dzt.p, h->mz.p, h->vz.p, nz, h->ctx, s));
+    HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, nullptr, nullptr, h->trace.p, s));
+    if (h->dump && h->dbg_it >= 0) {
+      unsigned long long* o = h->dump + (size_t)h->dbg_it * 16;
+      const float* bufs[12] = {h->yt.p, h->zt.p, h->u[0].p, h->v[0].p, h->u[1].p, h->u[2].p, h->g_yt_dist.p,
+                               h->g_yt_rate.p, h->g_zt_hs.p, h->g_zt_eb.p, h->y.p, h->z.p};
+      const int64_t ns[12] = {ny, nz, ny * 4, ny * 4, ny * 16, ny * 64, ny, ny, nz, nz, ny, nz};
+      for (int k = 0; k < 12; ++k) HIPCHK(h, launch_checksum(bufs[k], ns[k], o + k, s));
+    }
+    return SGA_OK;
+  };
+
+  bool graphed = false;
+  if (h->use_graph && !h->profiling) {
+    if (!h->graph_exec || h->graph_B != B || h->graph_H != H || h->graph_W != W ||
+        h->graph_relax != h->relax) {
+      if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const int rc = enqueue_step(st);
+        const hipError_t ec = hipStreamEndCapture(st, &graph);
+        if (rc == SGA_OK && ec == hipSuccess && graph &&
+            hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+          h->graph_B = B; h->graph_H = H; h->graph_W = W; h->graph_relax = h->relax;
+        } else {
+          h->graph_exec = nullptr;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+      }
+      (void)hipGetLastError();
+    }
+    graphed = h->graph_exec != nullptr;
+  }
+  for (int k = 0; k < n; ++k) {
+    h->dbg_it = h->run_it + k;
+    if (graphed) HIPCHK(h, hipGraphLaunch(h->graph_exec, st));
+    else SGACHK(enqueue_step(st));
+  }
+  h->dbg_it = -1;
+  h->run_it += n;
+  if (h->dump && h->run_it == its) {
+    std::vector<unsigned long long> host((size_t)its * 16);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host.data(), h->dump, host.size() * 8, hipMemcpyDeviceToHost);
+    char fn[512];
+    snprintf(fn, sizeof(fn), "%s.%d", h->dump_path, h->dump_run++);
+    if (FILE* f = fopen(fn, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+  }
+  if (h->dbg_fork) {
+    int bad = -1;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(&bad, h->dbg_bad, sizeof(int), hipMemcpyDeviceToHost);
+    int badj = -1;
+    (void)hipMemcpy(&badj, h->dbg_bad + 1, sizeof(int), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[sga debug] of %d iterations: side stream ahead of the fork %d, main stream ahead of the join %d\n",
+            n, bad, badj);
+    (void)hipMemset(h->dbg_bad, 0, 2 * sizeof(int));
+  }
+  return SGA_OK;
+}
+
+int sga_run_state(sga_handle* h, int set, float* y, float* z, float* trace, void* stream) {
+  if (!h || h->run_its < 0) return SGA_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(h->run_B, h->run_H, h->run_W);
+  const int64_t ny = (int64_t)h->run_B * g.yh * g.yw * h->C, nz = (int64_t)h->run_B * g.zh * g.zw * h->C;
+  if (set) {
+    if (!y || !z) return SGA_ERR_BAD_ARG;
+    HIPCHK(h, launch_copy(h->y.p, y, ny, st));
+    HIPCHK(h, launch_copy(h->z.p, z, nz, st));
+    return SGA_OK;
+  }
+  if (y) HIPCHK(h, launch_copy(y, h->y.p, ny, st));
+  if (z) HIPCHK(h, launch_copy(z, h->z.p, nz, st));
+  if (trace && h->run_it > 0) HIPCHK(h, launch_copy(trace, h->trace.p, (int64_t)h->run_it * 4, st));
+  return SGA_OK;
+}
+
+int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, float loss_scale,
+            int its, double lr, double annealing_rate, int t0, double T_ub, uint64_t seed,
+            const float* y0, const float* z0, float* y_hat, float* z_hat, float* metrics,
+            float* trace, void* stream) {
+  SGACHK(sga_run_begin(h, x, B, H, W, lambda, loss_scale, its, lr, annealing_rate, t0, T_ub, seed, y0, z0, stream));
+  SGACHK(sga_run_steps(h, its, stream));
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(B, H, W);
+  const int64_t ny = (int64_t)B * g.yh * g.yw * h->C, nz = (int64_t)B * g.zh * g.zw * h->C;
+  if (trace && its > 0) HIPCHK(h, launch_copy(trace, h->trace.p, (int64_t)((size_t)its * 4), st));
   // sga.py:240-247: round (half-to-even) and evaluate with the latents fed directly
   float* yh_dst = y_hat ? y_hat : h->g_yt_dist.p;
   float* zh_dst = z_hat ? z_hat : h->g_zt_hs.p;
   HIPCHK(h, launch_round(h->y.p, yh_dst, ny, st));
   HIPCHK(h, launch_round(h->z.p, zh_dst, nz, st));
   if (metrics) SGACHK(eval_impl(h, g, h->xin.p, yh_dst, zh_dst, metrics, nullptr, st));
+  return SGA_OK;
+}
+
+// tfc `_quantize(.., 'dequantize')` with centring, as map.py:83,101 uses it: z_hat = round(z - median)
+// + median; (mu, .) = h_s(z) with z AS GIVEN (map.py computes mu from the placeholder); y_hat =
+// round(y - mu) + mu.
+int sga_quantize_centered(sga_handle* h, const float* y, const float* z, int B, int H, int W,
+                          const float* medians, float* y_hat, float* z_hat, void* stream) {
+  if (!h || !y || !z || !y_hat || !z_hat) return SGA_ERR_BAD_ARG;
+  SGACHK(check_shape(h, B, H, W));
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(B, H, W);
+  const int C = h->C;
+  const int64_t nz = (int64_t)B * g.zh * g.zw * C;
+  h->cur_part = &h->part;
+  SGACHK(deconv_fwd(h, h->hs_f[0], h->hs_bias[0], z, B, g.zh, g.zw, h->hs0.p, EPI_BIAS_RELU, st));
+  SGACHK(deconv_fwd(h, h->hs_f[1], h->hs_bias[1], h->hs0.p, B, 2 * g.zh, 2 * g.zw, h->hs1.p, EPI_BIAS_RELU, st));
+  SGACHK(conv3(h, h->hs_f[2], h->hs_bias[2], h->hs1.p, h->C15, B, g.hsh, g.hsw, h->ms.p, true, EPI_BIAS, nullptr, st));
+  HIPCHK(h, launch_round_centered(y, h->ms.p, B, g.yh, g.yw, g.hsh, g.hsw, C, y_hat, st));
+  HIPCHK(h, launch_round_median(z, medians, nz, C, z_hat, st));
   return SGA_OK;
 }
 

@@ -108,6 +108,58 @@ def gather_metrics(local_idx, local_met, num_images, dist=None, device=None, nfi
     return out
 
 
+# hyper-parameters of the sibling scripts: (relaxation, schedule, lr, annealing_rate, T_ub, t0, early stop)
+SIBLINGS = {
+    "danneal": ("danneal", "exp", 0.005, 4e-3, 0.2, 0, False),    # danneal.py:183-193
+    "unoise": ("unoise", "exp0", 0.005, 1e-3, 0.5, 700, False),    # unoise.py:76,150-151 (no temperature)
+    "ste": ("ste", "exp0", 0.0001, 1e-3, 0.5, 700, True),          # ste.py:32,163-164
+    "map": ("none", "exp0", 0.005, 1e-3, 0.5, 700, True),          # map.py:32,153-154
+}
+
+
+def run_early_stop(codec, x, lmbda, *, method, its=2000, lr, seed=0, loss_scale=None, medians=None,
+                   check_itv=10, log=None):
+    """The early-stopping loops of map.py:167-199 and ste.py:177-203 on the device-resident run:
+    every `check_itv` iterations (it % 10 == 0, and the last one) look at the objective;
+    map: the objective AFTER centred rounding (y_hat = round(y - mu) + mu, z_hat = round(z - med) +
+    med, fed back without relaxation) must not get worse; ste: the training objective must improve.
+    Otherwise return to the latents of the previous check and stop.
+    Returns (y_hat, z_hat, metrics, iterations done)."""
+    import torch
+    B, H, W, _ = x.shape
+    if loss_scale is None:
+        loss_scale = 1.0 / B
+    codec.run_begin(x, lmbda, its=its, lr=lr, seed=seed, loss_scale=loss_scale)
+    prev, y_prev, z_prev, done = math.inf, None, None, 0
+    # the reference checks after iteration index it when it % 10 == 0 or it + 1 == its
+    checks = [i + 1 for i in range(its) if i % check_itv == 0 or i + 1 == its]
+    y_cur, z_cur = codec.run_latents()
+    it = 0
+    for nxt in checks:
+        codec.run_steps(nxt - it)
+        it = nxt
+        y_cur, z_cur, tr = codec.run_latents(trace=True)
+        if method == "map":
+            y_hat, z_hat = codec.quantize_centered(y_cur, z_cur, H, W, medians)
+            obj = codec.step_grads(x, y_hat, z_hat, 1.0, lmbda, loss_scale=loss_scale)["rd_loss"]
+            improved = obj <= prev                                # map.py:188
+        else:
+            obj = float(tr[it - 1, 0])                            # this iteration's training rd_loss
+            improved = obj < prev                                 # ste.py:189
+        if log:
+            log("it=%d obj=%.4f" % (it - 1, obj))
+        if improved:
+            prev, y_prev, z_prev, done = obj, y_cur, z_cur, it
+        else:
+            y_cur, z_cur = y_prev, z_prev
+            break
+    if method == "map":
+        y_hat, z_hat = codec.quantize_centered(y_cur, z_cur, H, W, medians)   # map.py:201
+    else:
+        y_hat, z_hat = torch.round(y_cur), torch.round(z_cur)                  # ste.py:201-202
+    return y_hat, z_hat, codec.evaluate(x, y_hat, z_hat), done
+
+
 def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=700, T_ub=0.5,
                 seed=0, rank=0, world=1, dist=None, verbose=False, log_itv=100, log=print,
                 method="sga", r_its=2000, r_lr=0.003):
@@ -131,6 +183,21 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
             elif method == "mbt2018":
                 _, _, met = codec.base_compress(X[idx])
                 tr = None
+            elif method in SIBLINGS:
+                relax, sched, s_lr, s_r, s_Tub, s_t0, early = SIBLINGS[method]
+                codec.set_relaxation(relax, sched)
+                try:
+                    if early:
+                        _, _, met, _ = run_early_stop(codec, X[idx], lmbda, method=method, its=its, lr=s_lr,
+                                                      seed=sd, loss_scale=loss_scale,
+                                                      log=log if verbose else None)
+                        tr = None
+                    else:
+                        _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=s_lr, annealing_rate=s_r,
+                                                  t0=s_t0, T_ub=s_Tub, seed=sd, loss_scale=loss_scale,
+                                                  trace=verbose)
+                finally:
+                    codec.set_relaxation("sga", "exp0")
             else:
                 _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate,
                                           t0=t0, T_ub=T_ub, seed=sd, loss_scale=loss_scale,
@@ -165,7 +232,7 @@ def parse_args(argv):
     c.add_argument("--sga_its", type=int, default=2000)
     c.add_argument("--annealing_rate", type=float, default=1e-3)
     c.add_argument("--t0", type=int, default=700)
-    c.add_argument("--method", default="sga", choices=["sga", "bb_sga", "mbt2018"],
+    c.add_argument("--method", default="sga", choices=["sga", "bb_sga", "mbt2018", "danneal", "unoise", "ste", "map"],
                    help="which reference script to mirror: sga.py, bb_sga.py or mbt2018.py compress")
     c.add_argument("--synthetic_weights", action="store_true",
                    help="use the deterministic synthetic parameters instead of a checkpoint")

@@ -124,6 +124,25 @@ int sga_run(sga_handle* h, const float* x, int B, int H, int W, float lambda, fl
             const float* y0, const float* z0,
             float* y_hat, float* z_hat, float* metrics, float* trace, void* stream);
 
+/* ---- the same loop in pieces, for the scripts that decide on the host while it runs --------
+ * map.py:167-196 and ste.py:177-194 stop early: every 10 iterations they look at the objective
+ * and either continue or go back to the latents of the previous check.  sga_run_begin = everything
+ * sga_run does before its loop (encode or y0/z0, fresh Adam state, schedules for `its` iterations);
+ * sga_run_steps = the next n iterations (same graph replay as sga_run); sga_run_state copies the
+ * current continuous latents and the trace so far out (set = 0) or overwrites the latents (set = 1).
+ * Other entry points (sga_step_grads, sga_eval, sga_quantize_centered) may be called in between. */
+int sga_run_begin(sga_handle* h, const float* x, int B, int H, int W, float lambda, float loss_scale,
+                  int its, double lr, double annealing_rate, int t0, double T_ub, uint64_t seed,
+                  const float* y0, const float* z0, void* stream);
+int sga_run_steps(sga_handle* h, int n, void* stream);
+int sga_run_state(sga_handle* h, int set, float* y, float* z, float* trace, void* stream);
+
+/* ---- tfc `_quantize(., 'dequantize')` with centring (map.py:83,101; mbt2018.py:69,80):
+ * z_hat = round(z - median) + median, y_hat = round(y - mu) + mu with (mu, .) = h_s(z), z as given.
+ * medians: [num_filters] device array or NULL (= 0). */
+int sga_quantize_centered(sga_handle* h, const float* y, const float* z, int B, int H, int W,
+                          const float* medians, float* y_hat, float* z_hat, void* stream);
+
 /* ---- sga.py:219-225,244-245  eval with the latents fed directly (no sampler) ------------ */
 int sga_eval(sga_handle* h, const float* x, int B, int H, int W,
              const float* y_hat, const float* z_hat, float* metrics, float* x_hat, void* stream);

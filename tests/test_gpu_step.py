@@ -255,6 +255,92 @@ def test_sibling_relaxations(mode, gpu_out_dir):
     assert abs(got["rd_loss"] - ref["rd_loss"]) <= 2e-5 * abs(ref["rd_loss"])
 
 
+def test_run_in_pieces_equals_run(gpu_out_dir):
+    """sga_run_begin + sga_run_steps(7) + (other entry points in between) + sga_run_steps(rest)
+    ends in exactly the latents of one sga_run call."""
+    C, B, H, W = 64, 2, 64, 64
+    codec, _, _ = setup(C, B, H, W)
+    x = image(B, H, W, seed=31)
+    y_ref, z_ref, _, tr_ref = codec.run(x, 0.01, its=30, t0=5, annealing_rate=0.02, seed=5, trace=True)
+    codec.run_begin(x, 0.01, its=30, t0=5, annealing_rate=0.02, seed=5)
+    codec.run_steps(7)
+    y7, z7 = codec.run_latents()
+    codec.step_grads(x, y7, z7, 0.3, 0.01)            # clobbers the step context and the sums
+    codec.evaluate(x, torch.round(y7), torch.round(z7))
+    codec.run_steps(1)
+    codec.run_steps(100)                               # clamps to the 22 iterations that are left
+    y, z, tr = codec.run_latents(trace=True)
+    assert torch.equal(torch.round(y), y_ref) and torch.equal(torch.round(z), z_ref)
+    assert torch.equal(tr[:30], tr_ref)
+    # restoring earlier latents really replaces the state
+    codec.run_set_latents(y7, z7)
+    y2, z2 = codec.run_latents()
+    assert torch.equal(y2, y7) and torch.equal(z2, z7)
+
+
+@pytest.mark.parametrize("method,lr", [("map", 0.005), ("ste", 0.05), ("map", 0.08), ("ste", 1.0)])
+def test_early_stopping_loops_vs_oracle(method, lr, gpu_out_dir):
+    """map.py:167-199 / ste.py:177-203 through driver.run_early_stop vs the same loop written with
+    the oracle's step: same stopping iteration, same transmitted latents (up to float32 flips)."""
+    from sga_amd import driver
+    from sga_amd.codec import metrics_to_dict
+    from oracle.sga_oracle import AdamF32
+    C, B, H, W = 64, 2, 64, 64
+    codec, orc, _ = setup(C, B, H, W)
+    x = image(B, H, W, seed=41)
+    relax, sched = driver.SIBLINGS[method][:2]
+    # lr: ste.py's own 1e-4 does not move in 60 iterations; the large values make the objective turn
+    # around so that the stop rule fires
+    its, lmbda = 60, 0.01
+    # ---- oracle loop
+    y, z = (t.numpy() for t in orc.encode(x))
+    opt = AdamF32(lr=lr)
+    prev, y_prev, z_prev, done_ref = np.inf, None, None, 0
+    uy, uz = np.full((y.size, 2), 0.5, np.float32), np.full((z.size, 2), 0.5, np.float32)   # unused by these modes
+
+    def centred(yc, zc):
+        z_hat = torch.round(torch.tensor(zc))
+        mu = orc.hyper_synthesis(torch.tensor(zc))[..., :C][:, :yc.shape[1], :yc.shape[2], :]
+        return (torch.round(torch.tensor(yc) - mu) + mu).numpy(), z_hat.numpy()
+
+    for it in range(its):
+        s = orc.step(x, y, z, 1.0, uy, uz, lmbda, mode=relax)
+        y, z = opt.update([y, z], [s["gy"].numpy(), s["gz"].numpy()])
+        if it % 10 == 0 or it + 1 == its:
+            if method == "map":
+                yh, zh = centred(y, z)
+                obj = orc.step(x, yh, zh, 1.0, uy, uz, lmbda, mode="none")["rd_loss"]
+                ok = obj <= prev
+            else:
+                obj = s["rd_loss"]
+                ok = obj < prev
+            if ok:
+                prev, y_prev, z_prev, done_ref = obj, y, z, it + 1
+            else:
+                y, z = y_prev, z_prev
+                break
+    y_hat_ref, z_hat_ref = centred(y, z) if method == "map" else (np.round(y), np.round(z))
+    # ---- HIP path
+    try:
+        codec.set_relaxation(relax, sched)
+        y_hat, z_hat, met, done = driver.run_early_stop(codec, x, lmbda, method=method, its=its, lr=lr)
+    finally:
+        codec.set_relaxation("sga", "exp0")
+    # map: y_hat = round(y - mu) + mu is not an integer; equal up to mu's float32 rounding unless
+    # the rounding decision itself flipped (difference ~ 1)
+    dy = np.abs(y_hat.cpu().numpy() - y_hat_ref)
+    frac = float((dy > 0.5).mean())
+    with open(os.path.join(gpu_out_dir, "parity_step.jsonl"), "a") as f:
+        f.write(json.dumps(dict(test="early_stop", method=method, lr=lr, done=done, done_ref=done_ref, frac_y_diff=frac,
+                                max_small_diff=float(dy[dy <= 0.5].max()))) + "\n")
+    assert dy[dy <= 0.5].max() < 1e-4 + 1e-5 * np.abs(y_hat_ref).max()
+    assert done == done_ref, (done, done_ref)
+    assert frac < 5e-3 and float((z_hat.cpu().numpy() != z_hat_ref).mean()) < 2e-2
+    m = metrics_to_dict(met)
+    mo = orc.evaluate(x, y_hat_ref, z_hat_ref)
+    assert np.allclose(m["est_bpp"], mo["est_bpp"], rtol=5e-3) and np.allclose(m["psnr"], mo["psnr"], atol=0.05)
+
+
 def test_bitstream_round_trip(gpu_out_dir):
     """Real bytes for (y_hat, z_hat): decode reproduces the latents exactly and the actual rate is
     within a few % of the estimated rate (mbt2018.py:211-222 reports both)."""
