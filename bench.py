@@ -98,7 +98,12 @@ def main():
                     help="skip the secondary measurement in the other precision mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the eager, hipEvent-timed leg the `roofline` object comes from (the command "
+                         "profiles/r01_c_roofline_leg_kernel_stats.csv was taken from with rocprofv3 --kernel-trace --stats)")
     args = ap.parse_args()
+    if args.roofline_only:
+        args.warmup, args.steps, args.no_cpu_baseline, args.no_alt_precision = 0, 0, True, True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -159,7 +164,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     n_images = world * B * args.steps
-    value = n_images / elapsed
+    value = n_images / elapsed if args.steps else 0.0
 
     # ---- roofline of the dominant kernel: live hipEvent timing over eager launches ----------
     roofline = None
@@ -223,7 +228,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(C, H, W, args.lmbda)
 
-    if rank == 0:
+    if rank == 0 and args.roofline_only:
+        print(json.dumps({"roofline_only": True, "roofline": roofline,
+                          "kernels": [dict(name=k["name"], launches=k["launches"], ms=round(k["ms_total"], 3))
+                                      for k in kernels]}), flush=True)
+    elif rank == 0:
         m = met.detach().cpu().numpy()
         line = {
             "metric": "images/sec for 2000-step SGA (num_filters=192, 256x256) + final BPP/PSNR match",
