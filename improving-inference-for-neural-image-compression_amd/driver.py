@@ -160,6 +160,29 @@ def run_early_stop(codec, x, lmbda, *, method, its=2000, lr, seed=0, loss_scale=
     return y_hat, z_hat, codec.evaluate(x, y_hat, z_hat), done
 
 
+def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, loss_scale, log_itv=100, log=print):
+    """sga.py:210-238 with --verbose: at every log point also feed the ROUNDED latents straight into
+    the graph (sga.py:219-225) and print both objectives.  The run pauses at the log points
+    (sga_run_steps); a rounded latent passes through the sampler unchanged (floor == ceil)."""
+    import torch
+    codec.run_begin(x, lmbda, its=its, lr=lr, annealing_rate=annealing_rate, t0=t0, T_ub=T_ub, seed=seed,
+                    loss_scale=loss_scale)
+    done = 0
+    y = z = None
+    for it in [i for i in range(its) if i % log_itv == 0 or i + 1 == its]:
+        codec.run_steps(it + 1 - done)
+        done = it + 1
+        y, z, tr = codec.run_latents(trace=True)
+        T = annealed_temperature(it, annealing_rate, T_ub, scheme="exp0", t0=t0)
+        r = codec.step_grads(x, torch.round(y), torch.round(z), T, lmbda, loss_scale=loss_scale)
+        t = tr[it].tolist()
+        log("it=%d, T=%.3f rd_loss=%.4f mse=%.3f bpp=%.4f psnr=%.4f\t after rounding: rd_loss=%.4f, bpp=%.4f psnr=%.4f"
+            % (it, T, t[0], t[1], t[2], t[3], r["rd_loss"], r["train_bpp"], float(r["psnr"].mean())))
+    if y is None:
+        y, z = codec.run_latents()
+    return codec.evaluate(x, torch.round(y), torch.round(z))                # sga.py:240-245
+
+
 def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=700, T_ub=0.5,
                 seed=0, rank=0, world=1, dist=None, verbose=False, log_itv=100, log=print,
                 method="sga", r_its=2000, r_lr=0.003):
@@ -198,6 +221,10 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
                                                   trace=verbose)
                 finally:
                     codec.set_relaxation("sga", "exp0")
+            elif verbose:
+                met = run_verbose(codec, X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate, t0=t0,
+                                  T_ub=T_ub, seed=sd, loss_scale=loss_scale, log_itv=log_itv, log=log)
+                tr = None
             else:
                 _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate,
                                           t0=t0, T_ub=T_ub, seed=sd, loss_scale=loss_scale,

@@ -278,6 +278,24 @@ def test_run_in_pieces_equals_run(gpu_out_dir):
     assert torch.equal(y2, y7) and torch.equal(z2, z7)
 
 
+def test_verbose_run_matches_plain_run(gpu_out_dir):
+    """driver.run_verbose (sga.py:216-236 with --verbose: pauses at the log points and also feeds the
+    rounded latents) ends in the same metrics as the uninterrupted run and prints the reference's line."""
+    import re
+    from sga_amd import driver
+    C, B, H, W = 64, 2, 64, 64
+    codec, _, _ = setup(C, B, H, W)
+    x = image(B, H, W, seed=51)
+    kw = dict(its=25, lr=0.005, annealing_rate=0.02, t0=5, T_ub=0.5, seed=8)
+    _, _, met_ref, _ = codec.run(x, 0.01, **kw)
+    lines = []
+    met = driver.run_verbose(codec, torch.tensor(x), 0.01, loss_scale=1.0 / B, log_itv=10, log=lines.append, **kw)
+    assert torch.allclose(met, met_ref, rtol=1e-6, atol=0, equal_nan=True)
+    assert [int(re.match(r"it=(\d+),", l).group(1)) for l in lines] == [0, 10, 20, 24]
+    pat = r"it=\d+, T=\d\.\d{3} rd_loss=[\d.]+ mse=[\d.]+ bpp=[\d.]+ psnr=[\d.]+\t after rounding: rd_loss=[\d.]+, bpp=[\d.]+ psnr=[\d.]+$"
+    assert all(re.match(pat, l) for l in lines), lines
+
+
 @pytest.mark.parametrize("method,lr", [("map", 0.005), ("ste", 0.05), ("map", 0.08), ("ste", 1.0)])
 def test_early_stopping_loops_vs_oracle(method, lr, gpu_out_dir):
     """map.py:167-199 / ste.py:177-203 through driver.run_early_stop vs the same loop written with
