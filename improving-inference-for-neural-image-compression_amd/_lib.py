@@ -108,6 +108,11 @@ def load_library(path: str | None = None):
             f"{p} not found: the HIP extension is not built. Run `python -c 'import "
             "__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the SGA hot path.")
+    # PyTorch-ROCm bundles its own libamdhip64; libsga_hip.so links the system one by soname.  The
+    # process must end up with ONE HIP runtime (device pointers and streams cross this boundary), so
+    # torch's is loaded first and the dynamic linker resolves ours to it.  Loading libsga_hip.so
+    # before torch gave two runtimes and `sga_create` -> SGA_ERR_NO_DEVICE on a GPU box.
+    import torch  # noqa: F401
     lib = C.CDLL(p)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported

@@ -33,6 +33,18 @@ def test_library_exports_every_declared_symbol():
     assert lib.sga_abi_version() == _lib.SGA_ABI_VERSION
 
 
+def test_one_hip_runtime_in_the_process():
+    """Loading the library (even before anyone imported torch, as build() does) must leave ONE
+    libamdhip64 mapped: torch's bundled copy.  Two copies gave SGA_ERR_NO_DEVICE on a GPU box."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import sga_amd; from sga_amd import _lib; _lib.load_library(); "
+            "print(sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+    libs = eval(out.strip().splitlines()[-1])
+    assert len(libs) == 1 and "torch" in libs[0], libs
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load_library(str(tmp_path / "libsga_hip.so"))
