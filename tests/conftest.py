@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """The built libraries are git-ignored: on a fresh checkout compile them first (hipcc cross-compiles
+    gfx950 without a GPU).  A failed build fails the session loudly; there is no CPU fallback."""
+    pkg = os.path.join(ROOT, "improving-inference-for-neural-image-compression_amd")
+    if not (os.path.exists(os.path.join(pkg, "libsga_hip.so")) and os.path.exists(os.path.join(pkg, "librans.so"))):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 @pytest.fixture(scope="session")
 def gpu_out_dir():
     d = os.path.join(ROOT, "gpurun_out")
