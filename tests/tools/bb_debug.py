@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, "/root/repo")
+import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import numpy as np, torch, sga_amd
 from sga_amd.codec import SGACodec
 from oracle.sga_oracle import SGAOracle

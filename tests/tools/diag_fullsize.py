@@ -1,7 +1,7 @@
 """GPU-box diagnostic: parity of one SGA step and of the encoder at the full bench size, and the
 GPU trace of a long run.  (tests/-style use of the oracle as checker.)"""
 import sys, os, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import sga_amd

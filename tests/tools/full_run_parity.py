@@ -2,14 +2,14 @@
 with identical Philox noise, and the seed-to-seed spread of the same run (calibrates what
 'final BPP within 1e-3 / PSNR within 0.01 dB' can mean for a stochastic optimiser).
 
-    python scripts/full_run_parity.py [C B H W] > gpurun_out/full_run_parity.json
+    python tests/tools/full_run_parity.py [C B H W] > gpurun_out/full_run_parity.json
 """
 import json
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import sga_amd
