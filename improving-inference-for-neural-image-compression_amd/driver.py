@@ -264,6 +264,8 @@ def parse_args(argv):
     c.add_argument("--synthetic_weights", action="store_true",
                    help="use the deterministic synthetic parameters instead of a checkpoint")
     c.add_argument("--max_batch", type=int, default=0, help="images per GPU launch (0 = reference batch)")
+    c.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+                   help="arithmetic of the conv contractions (DESIGN.md 3.1b); f32 = fp32 MFMA")
     c.add_argument("runname")
     c.add_argument("input_file")
     c.add_argument("output_file", nargs="?")
@@ -303,7 +305,7 @@ def compress(args, weights=None):
     per_rank = -(-min(bs, N) // world)
     max_batch = args.max_batch or per_rank
     codec = SGACodec(weights, args.num_filters, max_batch, H, W, device=f"cuda:{local_rank}",
-                     bits_back=bb)
+                     bits_back=bb, precision=getattr(args, "precision", "f32"))
     res = run_dataset(codec, X, args.lmbda, its=args.sga_its, annealing_rate=args.annealing_rate,
                       t0=args.t0, seed=args.seed, rank=rank, world=world, dist=dist,
                       verbose=args.verbose, method=method)

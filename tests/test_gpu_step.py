@@ -278,6 +278,36 @@ def test_run_in_pieces_equals_run(gpu_out_dir):
     assert torch.equal(y2, y7) and torch.equal(z2, z7)
 
 
+@pytest.mark.parametrize("method", ["sga", "mbt2018", "danneal", "unoise", "ste", "map", "bb_sga"])
+def test_driver_cli_end_to_end(method, tmp_path):
+    """`python -m sga_amd.driver ... compress <runname> <input.npy>` (sga.py:37-295 and siblings) on a
+    5-image uint8 .npy with synthetic weights: the result file has the reference's name and fields,
+    one row per image, and chunking by --max_batch does not change per-image results."""
+    from sga_amd import driver
+    from sga_amd.codec import EVAL_FIELDS, BB_EVAL_FIELDS
+    X = (np.random.RandomState(3).rand(5, 48, 64, 3) * 255).astype(np.uint8)
+    inp = tmp_path / "tiny.npy"
+    np.save(inp, X)
+    runname = "mbt2018-num_filters=64-lmbda=0.02"
+    res = {}
+    for mb in (5, 2):
+        out = tmp_path / f"res{mb}"
+        argv = ["--num_filters", "64", "compress", "--results_dir", str(out), "--sga_its", "12", "--t0", "4",
+                "--method", method, "--synthetic_weights", "--max_batch", str(mb), runname, str(inp)]
+        driver.main(argv)
+        files = os.listdir(out)
+        assert files == [driver.result_filename("rd", method, 0.02, runname, str(inp))], files
+        res[mb] = dict(np.load(out / files[0]))
+    fields = BB_EVAL_FIELDS if method == "bb_sga" else EVAL_FIELDS
+    assert sorted(res[5]) == sorted(fields)
+    for k in fields:
+        assert res[5][k].shape == (5,)
+    assert np.isfinite(res[5]["est_bpp"]).all() and np.isfinite(res[5]["psnr"]).all()
+    if method in ("mbt2018", "danneal", "ste", "map"):       # no noise: chunking cannot matter
+        for k in ("est_bpp", "psnr"):
+            assert np.allclose(res[5][k], res[2][k], rtol=2e-4), (k, res[5][k], res[2][k])
+
+
 def test_verbose_run_matches_plain_run(gpu_out_dir):
     """driver.run_verbose (sga.py:216-236 with --verbose: pauses at the log points and also feeds the
     rounded latents) ends in the same metrics as the uninterrupted run and prints the reference's line."""
