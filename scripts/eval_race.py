@@ -4,7 +4,7 @@ import os, sys, hashlib, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, sga_amd
 from sga_amd.codec import SGACodec
-C, B, H, W = 192, 8, 256, 256
+C, B, H, W = (int(v) for v in os.environ.get("SHAPE", "192,8,256,256").split(","))
 w = sga_amd.make_synthetic_weights(C, 0)
 x = torch.rand(B, H, W, 3, generator=torch.Generator().manual_seed(0)).numpy()
 its = int(os.environ.get("ITS", 300)); reruns = int(os.environ.get("RERUNS", 16))
