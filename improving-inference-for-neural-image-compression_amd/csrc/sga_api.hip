@@ -99,6 +99,8 @@ struct sga_handle {
   char x3_skip[128] = {0};         // SGA_X3_SKIP="gs0.fwd,gs1.bwd" (experiments)
   int run_B = 0, run_H = 0, run_W = 0, run_its = -1, run_it = 0;   // sga_run_begin/steps state
   float run_lambda = 0.f, run_loss_scale = 1.f; uint64_t run_seed = 0;
+  bool split256 = true;            // split-K also for a single-phase launch of exactly 256 tiles (SGA_SPLIT256=0: off)
+  bool bm256 = true;               // 256-row 8-wave tile for big unsplit f32 launches (SGA_BM256=0: off)
   int x3_mask = 3;                 // SGA_X3_MASK
   int dbg_delay_us = 0;            // SGA_DEBUG_DELAY_US: stall the side branch (experiments)
   bool fences = true;              // SGA_NO_FENCES=1 removes the one-wave kernels around fork/join
@@ -157,7 +159,7 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   if (a.out_coff != 0 || a.out_cs != a.Cout || (a.Cout & 3)) return 1;
   const int tiles = a.tiles_per_phase * a.ntiles_n;
   const int blocks = a.nphase * tiles;
-  if (blocks > 256 || (blocks == 256 && a.nphase == 1)) return 1;
+  if (blocks > 256 || (blocks == 256 && a.nphase == 1 && !h->split256)) return 1;
   // target: ~512 workgroups of (nearly) equal K length
   long long total_steps = 0;
   int steps[4] = {0, 0, 0, 0};
@@ -185,6 +187,14 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
 
 // every MFMA convolution goes through here (so it can be timed)
 int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st) {
+  // 256-row tile (8 waves): each weight byte feeds twice the MFMAs; only for big unsplit f32 launches
+  a.bm = 128;
+  if (h->bm256 && !h->x3 && !a.smallc && a.pro == PRO_NONE && a.Npad / a.ntiles_n == 192 &&
+      (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RELU_MASK) &&
+      (long long)a.nphase * a.tiles_per_phase * a.ntiles_n >= 1024) {
+    a.bm = 256;
+    a.tiles_per_phase = (a.tiles_per_phase + 1) / 2;
+  }
   a.ksplit = pick_ksplit(h, a);
   // bf16x3 where it is faster: the IGDN-backward prologue (3 prefetched operands) and the 2-wave
   // BN=96 tile spill to scratch in that mode and measured slower than their f32 instances (193 vs
@@ -972,6 +982,10 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     if (dev_alloc(h, &p, (size_t)kMaxIts * 16 * 8) != SGA_OK) return fail(SGA_ERR_NOMEM);
     h->dump = (unsigned long long*)p;
   }
+  env = getenv("SGA_SPLIT256");
+  h->split256 = !(env && env[0] == '0');
+  env = getenv("SGA_BM256");
+  h->bm256 = !(env && env[0] == '0');
   env = getenv("SGA_X3_SKIP");
   if (env) strncpy(h->x3_skip, env, sizeof(h->x3_skip) - 1);
   env = getenv("SGA_X3_MASK");

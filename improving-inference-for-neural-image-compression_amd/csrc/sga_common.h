@@ -82,6 +82,7 @@ struct ConvArgs {
   // split-K: grid = tiles x ksplit; split s multiplies K-steps [s*n/S, (s+1)*n/S) of its phase and
   // writes the raw accumulators to part + s*slab (output geometry); a fixed-order reduce kernel
   // then sums the slabs and applies the epilogue (deterministic, no atomics).
+  int bm;                  // rows per tile: 128 (default, 4 waves) or 256 (8 waves, big unsplit layers)
   int ksplit;              // max over phases of nsplit[] (1 = no split)
   int nsplit[4];           // per-phase split factor: phases differ in tap count (9/6/6/4), so each
   int blk_begin[4];        //   gets splits in proportion and all workgroups walk ~equal K
