@@ -45,6 +45,21 @@ def test_one_hip_runtime_in_the_process():
     assert len(libs) == 1 and "torch" in libs[0], libs
 
 
+def test_header_is_plain_c_and_client_compiles(tmp_path):
+    """include/sga_hip.h must be consumable from C (the boundary has no C++ or torch types): compile
+    the plain-C client against it and link it with the built library (no GPU needed to link)."""
+    import subprocess
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    hdr_only = tmp_path / "h.c"
+    hdr_only.write_text('#include "sga_hip.h"\nint main(void) { return sga_abi_version() == SGA_ABI_VERSION ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c",
+                    str(hdr_only), "-o", str(tmp_path / "h.o")], check=True)
+    subprocess.run(["gcc", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.join(rocm, "include"), os.path.join(ROOT, "tests", "c_client", "sga_client.c"),
+                    "-o", str(tmp_path / "client"), "-L", PKG, "-lsga_hip", "-L", os.path.join(rocm, "lib"),
+                    "-lamdhip64", f"-Wl,-rpath,{PKG}:{os.path.join(rocm, 'lib')}"], check=True)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load_library(str(tmp_path / "libsga_hip.so"))
