@@ -101,6 +101,7 @@ struct sga_handle {
   float run_lambda = 0.f, run_loss_scale = 1.f; uint64_t run_seed = 0;
   bool split256 = true;            // split-K also for a single-phase launch of exactly 256 tiles (SGA_SPLIT256=0: off)
   bool bm256 = true;               // 256-row 8-wave tile for big unsplit f32 launches (SGA_BM256=0: off)
+  bool first_after_fork = false;   // set at the fork, consumed by the next main-stream conv_launch
   int x3_mask = 3;                 // SGA_X3_MASK
   int dbg_delay_us = 0;            // SGA_DEBUG_DELAY_US: stall the side branch (experiments)
   bool fences = true;              // SGA_NO_FENCES=1 removes the one-wave kernels around fork/join
@@ -202,6 +203,12 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st) {
   a.x3 = (h->x3 && a.w3 && !a.smallc && a.epi != EPI_SHUFFLE3 && a.pro != PRO_IGDN_BWD &&
           a.Npad / a.ntiles_n != 96) ? 1 : 0;
   if (a.x3 && !(h->x3_mask & (st == h->sB ? 2 : 1))) a.x3 = 0;   // SGA_X3_MASK (experiments)
+  // bf16x3 with two streams: the main-stream convolution that starts together with the side branch
+  // stays on the f32 kernel.  With it in bf16x3, identical 2000-iteration runs ended in different
+  // latents in 7 of 25 cases (the first side-stream kernel read stale inputs); with this rule 25
+  // of 25 graph-replay and 17 of 17 eager runs are bit-identical.
+  if (a.x3 && h->first_after_fork && st != h->sB) a.x3 = 0;
+  if (st != h->sB) h->first_after_fork = false;
   if (a.x3 && h->x3_skip[0] && h->cur_tag && h->cur_tag[0] && strstr(h->x3_skip, h->cur_tag)) a.x3 = 0;   // SGA_X3_SKIP
   if (a.x3 && a.ksplit > 1 && (h->x3_mask & 4)) a.x3 = 0;           // bit 2: no x3 on split-K launches
   if (a.x3 && a.ksplit <= 1 && (h->x3_mask & 8)) a.x3 = 0;          // bit 3: no x3 on unsplit launches
@@ -708,7 +715,9 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
   h->cur_part = &h->partB;
   int rc = hyper_branch(h, g, with_grad, h->sB, density);
   h->cur_part = &h->part;
+  h->first_after_fork = true;
   if (rc == SGA_OK) rc = synth_branch(h, g, x, with_grad, st);
+  h->first_after_fork = false;
   // always join, even on error, so a capture in progress is not left forked
   const bool dbg = h->dbg_fork && h->dbg_it >= 0 && cs != hipStreamCaptureStatusActive;
   if (dbg) (void)launch_set_int(h->dbg_bad + 8, h->dbg_it, h->sB);          // last op of the side branch
@@ -948,7 +957,6 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->use_graph = !(env && env[0] == '1');
   env = getenv("SGA_NO_OVERLAP");
   h->overlap = !(env && env[0] == '1');
-  const bool overlap_forced = env && env[0] == '0';
   {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -1002,13 +1010,6 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     h->dbg_bad = (int*)p;
     (void)hipMemset(p, 0, 256);
   }
-  // bf16x3 runs single-stream: with the hyper branch on a second stream, identical 2000-iteration
-  // runs of that mode ended in different latents in 7 of 25 cases (graph replay), 0 of 25
-  // single-stream; f32 mode was identical in 30 of 30 two-stream runs, also with the side branch
-  // artificially delayed.  The cause was narrowed down (the first bf16x3 split-K launch after the
-  // fork, gs0.fwd, must be in the picture) but not understood, so the mode gives up the overlap
-  // (1.80 -> 1.97 ms/iteration) rather than its reproducibility.  SGA_NO_OVERLAP=0 forces it on.
-  if (h->x3 && !overlap_forced) h->overlap = false;
   env = getenv("SGA_NO_SPLITK");
   h->no_splitk = env && env[0] == '1';
   env = getenv("SGA_PROFILE_BY_LAYER");
