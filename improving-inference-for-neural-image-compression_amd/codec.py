@@ -40,6 +40,10 @@ class SGACodec:
         self.bits_back = bool(bits_back)
         check_weights(weights, self.C, bits_back)
         self._weights_for_ec = {k: v for k, v in weights.items() if k.startswith("eb.")}
+        # medians of the factorized prior (tfc `quantiles[:, 0, 1]`): centre of the rounding in
+        # mbt2018.py:69 / map.py:83; None for synthetic weights (= 0)
+        med = weights.get("eb.medians")
+        self.medians = None if med is None else np.ascontiguousarray(med, dtype=np.float32).reshape(self.C)
         self._ec = None
         self.max_batch, self.max_height, self.max_width = int(max_batch), int(max_height), int(max_width)
         torch.cuda.set_device(self.device)
@@ -121,6 +125,13 @@ class SGACodec:
         """Sibling inference methods on the same step (danneal.py / unoise.py / ste.py / map.py)."""
         self._chk(self.lib.sga_set_relaxation(self.handle, _lib.RELAXATIONS[relaxation],
                                               _lib.SCHEDULES[schedule]), "sga_set_relaxation")
+
+    def set_image_ids(self, ids=None):
+        """Positions of this codec's images in their reference batch (None: 0,1,2,...): the device
+        noise of image b is then the noise position ids[b] draws in the un-sharded batch."""
+        ids = [] if ids is None else [int(i) for i in ids]
+        arr = (C.c_int32 * max(len(ids), 1))(*ids)
+        self._chk(self.lib.sga_set_image_ids(self.handle, arr, len(ids)), "sga_set_image_ids")
 
     # ---- the session interactions ------------------------------------------------------------
     def encode(self, x):

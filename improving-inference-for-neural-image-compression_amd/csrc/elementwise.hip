@@ -53,7 +53,8 @@ __device__ __forceinline__ float sgnf(float t) { return (t > 0.f) - (t < 0.f); }
 // ------------------------------------------------------------------------------------------
 __global__ void k_sample(const float* __restrict__ v, const float* __restrict__ u,
                          const StepCtx* __restrict__ ctx, int stream_id, float* __restrict__ vt,
-                         float* __restrict__ dvt, int64_t n, int mode) {
+                         float* __restrict__ dvt, int64_t n, int mode,
+                         const int* __restrict__ img_ids, int64_t per_img) {
   const float T = ctx->T;
   const int it = ctx->it;
   const unsigned k0 = ctx->seed_lo, k1 = ctx->seed_hi;
@@ -65,7 +66,14 @@ __global__ void k_sample(const float* __restrict__ v, const float* __restrict__ 
       u1 = u[2 * idx + 1];
     } else {
       uint32_t r[4];
-      philox4x32_10((uint32_t)idx, (uint32_t)((uint64_t)idx >> 32), (uint32_t)it,
+      // counter = element index within the REFERENCE batch: image img_ids[b] of it (sga_set_image_ids),
+      // so a shard draws the noise its images would have drawn in the un-sharded batch
+      int64_t ctr = idx;
+      if (img_ids) {
+        const int64_t b = idx / per_img;
+        ctr = (int64_t)img_ids[b] * per_img + (idx - b * per_img);
+      }
+      philox4x32_10((uint32_t)ctr, (uint32_t)((uint64_t)ctr >> 32), (uint32_t)it,
                     (uint32_t)stream_id, k0, k1, r);
       u0 = bits_to_uniform(r[0]);
       u1 = bits_to_uniform(r[1]);
@@ -285,9 +293,10 @@ __global__ void k_factorized_pdf(const float* __restrict__ zt, const float* __re
 __global__ void k_bb_sample_z(const float* __restrict__ zml, const float* __restrict__ eps_in,
                               const StepCtx* __restrict__ ctx, int stream_id, int n_per_img, int C,
                               float* __restrict__ zt, float* __restrict__ jac_lv,
-                              ImgSums* __restrict__ sums) {
+                              ImgSums* __restrict__ sums, const int* __restrict__ img_ids) {
   __shared__ double sh[16];
   const int b = blockIdx.y;
+  const size_t ctr_base = (size_t)(img_ids ? img_ids[b] : b) * n_per_img;
   const int it = ctx->it;
   const unsigned k0 = ctx->seed_lo, k1 = ctx->seed_hi;
   double acc[1] = {0.0};
@@ -301,7 +310,8 @@ __global__ void k_bb_sample_z(const float* __restrict__ zml, const float* __rest
       ep = eps_in[idx];
     } else {
       uint32_t r[4];
-      philox4x32_10((uint32_t)idx, (uint32_t)((uint64_t)idx >> 32), (uint32_t)it,
+      const size_t ctr = ctr_base + e;
+      philox4x32_10((uint32_t)ctr, (uint32_t)((uint64_t)ctr >> 32), (uint32_t)it,
                     (uint32_t)stream_id, k0, k1, r);
       const float u1 = bits_to_uniform(r[2]), u2 = bits_to_uniform(r[3]);
       ep = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864769f * u2);   // Box-Muller
@@ -696,9 +706,9 @@ inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
 #define LAUNCH_RET() return (int)hipGetLastError()
 
 int launch_sample(const float* v, const float* u, const StepCtx* ctx, int stream_id, float* vt,
-                  float* dvt, int64_t n, hipStream_t s, int mode) {
+                  float* dvt, int64_t n, hipStream_t s, int mode, const int* img_ids, int64_t per_img) {
   hipLaunchKernelGGL(k_sample, dim3(grid_for(n)), dim3(256), 0, s, v, u, ctx, stream_id, vt, dvt, n,
-                     mode);
+                     mode, img_ids, per_img > 0 ? per_img : n);
   LAUNCH_RET();
 }
 
@@ -851,10 +861,10 @@ int launch_relu_mask(const float* g, const float* act, float* out, int64_t n, hi
 
 int launch_bb_sample_z(const float* zml, const float* eps_in, const StepCtx* ctx, int stream_id,
                        int B, int npix, int C, float* zt, float* jac_lv, ImgSums* sums,
-                       hipStream_t s) {
+                       hipStream_t s, const int* img_ids) {
   const int n_per_img = npix * C;
   hipLaunchKernelGGL(k_bb_sample_z, dim3(grid_for(n_per_img, 256, 256), B), dim3(256), 0, s, zml,
-                     eps_in, ctx, stream_id, n_per_img, C, zt, jac_lv, sums);
+                     eps_in, ctx, stream_id, n_per_img, C, zt, jac_lv, sums, img_ids);
   LAUNCH_RET();
 }
 

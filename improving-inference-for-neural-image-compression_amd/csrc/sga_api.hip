@@ -110,6 +110,7 @@ struct sga_handle {
   bool overlap = true;             // SGA_NO_OVERLAP=1 disables
   ImgSums* sums = nullptr;
   StepCtx* ctx = nullptr;
+  int* img_ids = nullptr;        // [max_batch] position of each image in its reference batch (sga_set_image_ids)
   std::vector<float> hT, hLr;    // host tables (kept alive across the async upload)
 
   Geom geom_zeroed;              // geometry for which xpad/gpad borders are known zero
@@ -735,8 +736,8 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
 int sga_step_core(sga_handle* h, const Geom& g, const float* x, const float* y, const float* z,
                   const float* u_y, const float* u_z, hipStream_t st) {
   const int64_t ny = (int64_t)g.B * g.yh * g.yw * h->C, nz = (int64_t)g.B * g.zh * g.zw * h->C;
-  HIPCHK(h, launch_sample(z, u_z, h->ctx, 1, h->zt.p, h->dzt.p, nz, st, h->relax));
-  HIPCHK(h, launch_sample(y, u_y, h->ctx, 0, h->yt.p, h->dyt.p, ny, st, h->relax));
+  HIPCHK(h, launch_sample(z, u_z, h->ctx, 1, h->zt.p, h->dzt.p, nz, st, h->relax, h->img_ids, nz / g.B));
+  HIPCHK(h, launch_sample(y, u_y, h->ctx, 0, h->yt.p, h->dyt.p, ny, st, h->relax, h->img_ids, ny / g.B));
   return rd_forward_backward(h, g, x, true, st);
 }
 
@@ -951,6 +952,11 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     TRY(dev_alloc(h, &p, sizeof(StepCtx)));
     h->ctx = (StepCtx*)p;
     if (hipMemset(p, 0, sizeof(StepCtx)) != hipSuccess) return fail(SGA_ERR_HIP);
+    TRY(dev_alloc(h, &p, sizeof(int) * B));
+    h->img_ids = (int*)p;
+    std::vector<int> ident(B);
+    for (size_t i = 0; i < B; ++i) ident[i] = (int)i;
+    if (hipMemcpy(p, ident.data(), sizeof(int) * B, hipMemcpyHostToDevice) != hipSuccess) return fail(SGA_ERR_HIP);
   }
   if (hipDeviceSynchronize() != hipSuccess) return fail(SGA_ERR_HIP);
   const char* env = getenv("SGA_NO_GRAPH");
@@ -1043,6 +1049,20 @@ int sga_latent_shape(const sga_handle* h, int H, int W, int* yh, int* yw, int* z
   if (yw) *yw = g.yw;
   if (zh) *zh = g.zh;
   if (zw) *zw = g.zw;
+  return SGA_OK;
+}
+
+int sga_set_image_ids(sga_handle* h, const int32_t* ids, int n) {
+  if (!h || n < 0 || n > h->cfg.max_batch || (n > 0 && !ids)) return SGA_ERR_BAD_ARG;
+  std::vector<int> v(h->cfg.max_batch);
+  for (int i = 0; i < h->cfg.max_batch; ++i) {
+    v[i] = i < n ? ids[i] : i;
+    if (v[i] < 0) return SGA_ERR_BAD_ARG;
+  }
+  // the captured step graph reads this array through a fixed device pointer: wait for work in
+  // flight, then overwrite the contents (no re-capture needed)
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(h->img_ids, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
   return SGA_OK;
 }
 
@@ -1483,10 +1503,10 @@ int bb_step_core(sga_handle* h, const Geom& g, const float* x, const float* y, c
     if (y != h->yt.p)
       HIPCHK(h, launch_copy(h->yt.p, y, (int64_t)(ny), st));
   } else {
-    HIPCHK(h, launch_sample(y, u_y, h->ctx, 0, h->yt.p, h->dyt.p, ny, st));
+    HIPCHK(h, launch_sample(y, u_y, h->ctx, 0, h->yt.p, h->dyt.p, ny, st, 0, h->img_ids, ny / g.B));
   }
   HIPCHK(h, launch_bb_sample_z(zml, eps, h->ctx, eps_stream, g.B, g.zh * g.zw, C, h->zt.p,
-                               h->jac_lv.p, h->sums, st));
+                               h->jac_lv.p, h->sums, st, h->img_ids));
   SGACHK(rd_forward_backward(h, g, x, true, st, /*density=*/true, /*do_synth=*/!rate_only));
   HIPCHK(h, launch_bb_zgrad(h->g_zt_hs.p, h->g_zt_eb.p, h->jac_lv.p, h->ctx, inv_ln2_hw(g),
                             (int64_t)g.B * g.zh * g.zw, C, h->g_zml.p, st));
@@ -1500,7 +1520,8 @@ int bb_eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_ha
   HIPCHK(h, launch_fill((float*)h->sums, 0.f, (int64_t)(sizeof(ImgSums) / sizeof(float)) * (g.B), st));
   if (y_hat != h->yt.p)
     HIPCHK(h, launch_copy(h->yt.p, y_hat, (int64_t)(ny), st));
-  HIPCHK(h, launch_bb_sample_z(zml, eps, h->ctx, 3, g.B, g.zh * g.zw, C, h->zt.p, nullptr, h->sums, st));
+  HIPCHK(h, launch_bb_sample_z(zml, eps, h->ctx, 3, g.B, g.zh * g.zw, C, h->zt.p, nullptr, h->sums, st,
+                               h->img_ids));
   SGACHK(rd_forward_backward(h, g, x, false, st, true, true));
   if (metrics) {
     HIPCHK(h, launch_finalize_eval_bb(h->sums, g.B, g.H, g.W, metrics, st));

@@ -75,9 +75,11 @@ def reference_batches(num_images: int, batch_size: int):
     return [list(range(s, min(s + batch_size, num_images))) for s in range(0, num_images, batch_size)]
 
 
-def shard_batch(indices, rank: int, world: int):
-    """Round-robin deal of one reference batch to the ranks."""
-    return indices[rank::world]
+def shard_batch(indices, rank: int, world: int, batch_no: int = 0):
+    """Round-robin deal of one reference batch to the ranks.  The rank that gets the first image
+    rotates with the batch number so that ragged batches (len % world != 0) do not always load
+    the low ranks (Tecnick: 100 images in batches of 7 on 8 GPUs)."""
+    return indices[(rank - batch_no) % world::world]
 
 
 def gather_metrics(local_idx, local_met, num_images, dist=None, device=None, nfields=None):
@@ -86,14 +88,18 @@ def gather_metrics(local_idx, local_met, num_images, dist=None, device=None, nfi
     import torch
     nfields = nfields or len(EVAL_FIELDS)
     out = np.full((num_images, nfields), np.nan, np.float32)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         if len(local_idx):
             out[np.asarray(local_idx)] = local_met
         return out
     world = dist.get_world_size()
-    cap = -(-num_images // world) + 1            # same padded size on every rank
-    buf = torch.full((cap, nfields + 1), -1.0, dtype=torch.float32)
     n = len(local_idx)
+    # same padded size on every rank: the largest local count (a rank's share is not bounded by
+    # ceil(N / world): every ragged reference batch can give it one image more than the others)
+    cnt = torch.tensor([n], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+    cap = max(int(cnt.item()), 1)
+    buf = torch.full((cap, nfields + 1), -1.0, dtype=torch.float32)
     if n:
         buf[:n, 0] = torch.as_tensor(np.asarray(local_idx, np.float32))
         buf[:n, 1:] = torch.as_tensor(np.asarray(local_met, np.float32))
@@ -163,7 +169,7 @@ def run_early_stop(codec, x, lmbda, *, method, its=2000, lr, seed=0, loss_scale=
 def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, loss_scale, log_itv=100, log=print):
     """sga.py:210-238 with --verbose: at every log point also feed the ROUNDED latents straight into
     the graph (sga.py:219-225) and print both objectives.  The run pauses at the log points
-    (sga_run_steps); a rounded latent passes through the sampler unchanged (floor == ceil)."""
+    (sga_run_steps); the rounded latents are evaluated with the relaxation switched off."""
     import torch
     codec.run_begin(x, lmbda, its=its, lr=lr, annealing_rate=annealing_rate, t0=t0, T_ub=T_ub, seed=seed,
                     loss_scale=loss_scale)
@@ -174,7 +180,12 @@ def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, los
         done = it + 1
         y, z, tr = codec.run_latents(trace=True)
         T = annealed_temperature(it, annealing_rate, T_ub, scheme="exp0", t0=t0)
-        r = codec.step_grads(x, torch.round(y), torch.round(z), T, lmbda, loss_scale=loss_scale)
+        # sga.py:219-225 feeds y_tilde / z_tilde directly, i.e. past the sampler
+        codec.set_relaxation("none", "exp0")
+        try:
+            r = codec.step_grads(x, torch.round(y), torch.round(z), T, lmbda, loss_scale=loss_scale)
+        finally:
+            codec.set_relaxation("sga", "exp0")
         t = tr[it].tolist()
         log("it=%d, T=%.3f rd_loss=%.4f mse=%.3f bpp=%.4f psnr=%.4f\t after rounding: rd_loss=%.4f, bpp=%.4f psnr=%.4f"
             % (it, T, t[0], t[1], t[2], t[3], r["rd_loss"], r["train_bpp"], float(r["psnr"].mean())))
@@ -185,7 +196,7 @@ def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, los
 
 def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=700, T_ub=0.5,
                 seed=0, rank=0, world=1, dist=None, verbose=False, log_itv=100, log=print,
-                method="sga", r_its=2000, r_lr=0.003):
+                method="sga", r_its=2000, r_lr=0.003, medians=None):
     """The per-batch loop of sga.py:201-253 (method "sga"), bb_sga.py:199-280 ("bb_sga") or the
     one-shot mbt2018.py:159-180 ("mbt2018") over a dataset X [N,H,W,3] float32.
     Returns dict field -> [N] array (on every rank)."""
@@ -193,26 +204,33 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
     N, H, W, _ = X.shape
     bs = get_eval_batch_size(H * W)
     local_idx, local_met = [], []
+    if method in ("mbt2018", "map") and medians is None:
+        medians = getattr(codec, "medians", None)       # from the checkpoint's `quantiles`
+    log_sched, log_rate, log_Tub, log_t0 = "exp0", annealing_rate, T_ub, t0
     for b_i, batch in enumerate(reference_batches(N, bs)):
-        mine = shard_batch(batch, rank, world)
+        mine = shard_batch(batch, rank, world, b_i)
         loss_scale = 1.0 / len(batch)                   # the batch means of sga.py:147,150
+        # one noise stream per reference batch; an image's noise is keyed on its position in that
+        # batch (sga_set_image_ids), so results do not depend on world size or chunking
+        sd = seed + 1000003 * b_i
         for s in range(0, len(mine), codec.max_batch):  # workspace-sized chunks of the shard
             idx = mine[s:s + codec.max_batch]
-            sd = seed + 1000003 * b_i + s
+            codec.set_image_ids([i - batch[0] for i in idx])
             if method == "bb_sga":
                 _, _, met, tr, _ = codec.bb_run(X[idx], lmbda, its=its, r_its=r_its, lr=lr, r_lr=r_lr,
                                                 annealing_rate=annealing_rate, t0=t0, T_ub=T_ub,
                                                 seed=sd, loss_scale=loss_scale, trace=verbose)
             elif method == "mbt2018":
-                _, _, met = codec.base_compress(X[idx])
+                _, _, met = codec.base_compress(X[idx], medians=medians)
                 tr = None
             elif method in SIBLINGS:
                 relax, sched, s_lr, s_r, s_Tub, s_t0, early = SIBLINGS[method]
+                log_sched, log_rate, log_Tub, log_t0 = sched, s_r, s_Tub, s_t0
                 codec.set_relaxation(relax, sched)
                 try:
                     if early:
                         _, _, met, _ = run_early_stop(codec, X[idx], lmbda, method=method, its=its, lr=s_lr,
-                                                      seed=sd, loss_scale=loss_scale,
+                                                      seed=sd, loss_scale=loss_scale, medians=medians,
                                                       log=log if verbose else None)
                         tr = None
                     else:
@@ -233,11 +251,12 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
                 tr = tr.cpu().numpy()
                 for it in range(its):
                     if it % log_itv == 0 or it + 1 == its:      # sga.py:216,232-233
-                        T = annealed_temperature(it, annealing_rate, T_ub, scheme="exp0", t0=t0)
+                        T = annealed_temperature(it, log_rate, log_Tub, scheme=log_sched, t0=log_t0)
                         log("it=%d, T=%.3f rd_loss=%.4f mse=%.3f bpp=%.4f psnr=%.4f" %
                             (it, T, tr[it, 0], tr[it, 1], tr[it, 2], tr[it, 3]))
             local_idx += idx
             local_met.append(met.cpu().numpy())
+    codec.set_image_ids(None)
     local_met = np.concatenate(local_met, 0) if local_met else np.zeros((0, len(fields)), np.float32)
     device = codec.device if (dist is not None and dist.is_initialized()
                               and dist.get_backend() == "nccl") else None
@@ -301,6 +320,9 @@ def compress(args, weights=None):
             from .tf_checkpoint import load_effective_weights
             weights = load_effective_weights(os.path.join(args.checkpoint_dir, args.runname),
                                              args.num_filters, bb=bb)
+            if method in ("mbt2018", "map") and "eb.medians" not in weights:
+                raise SystemExit(f"--method {method} rounds z around the prior's medians (mbt2018.py:69, "
+                                 "map.py:83) but the checkpoint has no entropy_bottleneck/quantiles")
     bs = get_eval_batch_size(H * W)
     per_rank = -(-min(bs, N) // world)
     max_batch = args.max_batch or per_rank

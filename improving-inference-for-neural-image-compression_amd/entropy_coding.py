@@ -180,8 +180,20 @@ class EntropyCoder:
         return sym
 
     # ---- public API -----------------------------------------------------------------------------
+    @staticmethod
+    def _integers(v, what):
+        """The coder codes INTEGER latents (SGA's y_hat = round(y), sga.py:240-241).  Mean- or median-
+        centred latents (round(y - mu) + mu, mbt2018.py:69,80) are not integers: refuse them instead of
+        silently coding something else than what was passed in."""
+        v = np.asarray(v)
+        r = np.rint(v)
+        if not np.array_equal(r, v):
+            raise ValueError(f"{what} must hold integers (got max |v - rint(v)| = "
+                             f"{float(np.abs(v - r).max()):.3g}); centred latents are not supported by this coder")
+        return r
+
     def encode_z(self, z_hat) -> bytes:
-        z = np.rint(np.asarray(z_hat)).astype(np.int32)
+        z = self._integers(z_hat, "z_hat").astype(np.int32)
         tab = np.broadcast_to(np.arange(self.C, dtype=np.int32), z.shape)
         return self._run_encode(z, tab)
 
@@ -191,7 +203,7 @@ class EntropyCoder:
 
     def encode_y(self, y_hat, mu, sigma) -> bytes:
         r0, tab = self._y_symbols(y_hat, mu, sigma)
-        return self._run_encode(np.rint(np.asarray(y_hat)).astype(np.int32) - r0, tab)
+        return self._run_encode(self._integers(y_hat, "y_hat").astype(np.int32) - r0, tab)
 
     def decode_y(self, data: bytes, mu, sigma) -> np.ndarray:
         r0, tab = self._y_symbols(None, mu, sigma)

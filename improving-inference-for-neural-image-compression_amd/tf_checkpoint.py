@@ -301,6 +301,14 @@ def effective_weights_from_tensors(tensors: dict, num_filters: int, bb: bool = F
             w[f"eb.f{k}"] = np.tanh(_find(tensors, prior, f"factor_{k}")).astype(np.float32)
     for name, shp in shapes.items():
         w[name] = np.ascontiguousarray(w[name].reshape(shp), dtype=np.float32)
+    # tfc 1.3 EntropyBottleneck keeps `quantiles` (C,1,3) = (lower tail, MEDIAN, upper tail); the
+    # median centres the rounding of `_quantize(z, 'dequantize')` (mbt2018.py:69, map.py:83).  The
+    # bits-back prior (learned_prior.BMSHJ2018Prior) has no such variable.
+    try:
+        q = _find(tensors, prior, "quantiles")
+        w["eb.medians"] = np.ascontiguousarray(np.asarray(q, np.float32).reshape(C, -1)[:, 1])
+    except KeyError:
+        pass
     check_weights(w, C, bb)
     return w
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGA_ABI_VERSION 1
+#define SGA_ABI_VERSION 2
 
 typedef enum sga_status {
   SGA_OK = 0,
@@ -90,6 +90,15 @@ int sga_destroy(sga_handle* h);
 int sga_last_error(const sga_handle* h, char* msg, int msg_len);
 /* latent geometry for an HxW image: y is [h,w,C], z is [hz,wz,C] (sga.py:77-78) */
 int sga_latent_shape(const sga_handle* h, int H, int W, int* yh, int* yw, int* zh, int* zw);
+
+/* ---- sharding: which images of the reference batch does this handle hold? ----
+ * The reference draws the Gumbel noise of a whole batch from one op (sga.py:95-97,118-120), so an
+ * image's noise depends on its position in the batch.  ids[b] = position of the handle's b-th image
+ * in its reference batch (HOST pointer, n <= max_batch; n = 0 restores 0,1,2,...).  The device RNG
+ * keys element e of image b on ids[b] * elements_per_image + e, which makes a shard's results equal
+ * to the same images' results in the un-sharded batch bit for bit, for any world size or chunking.
+ * Synchronises the device. */
+int sga_set_image_ids(sga_handle* h, const int32_t* ids, int n);
 
 /* ---- sga.py:207  y_init, z_init = sess.run([y_init, z_init], {x}) ---------------------- */
 int sga_encode(sga_handle* h, const float* x, int B, int H, int W,

@@ -153,39 +153,57 @@ def test_bench_flop_model_matches_survey():
 # ---- multi-process sharding + gather under gloo (world_size 2) ---------------------------------
 class _FakeCodec:
     """Test stand-in with the SGACodec.run signature: metrics are a deterministic function of
-    the image and loss_scale, so sharded == unsharded can be checked without a GPU."""
+    the image, loss_scale, the image's position in its reference batch (set_image_ids) and the
+    seed, so sharded == unsharded can be checked without a GPU."""
     def __init__(self, max_batch):
         self.max_batch = max_batch
         self.device = torch.device("cpu")
+        self.ids = None
 
-    def run(self, x, lmbda, its=2000, loss_scale=None, trace=False, **kw):
+    def set_image_ids(self, ids=None):
+        self.ids = None if ids is None else [int(i) for i in ids]
+
+    def run(self, x, lmbda, its=2000, loss_scale=None, trace=False, seed=0, **kw):
         x = torch.as_tensor(x)
-        m = torch.stack([x.mean((1, 2, 3)) * (k + 1) + loss_scale for k in range(7)], dim=1)
+        ids = torch.tensor(self.ids if self.ids is not None else list(range(len(x))), dtype=torch.float32)
+        assert len(ids) == len(x)
+        base = x.mean((1, 2, 3)) + loss_scale + 1e-3 * ids + 1e-5 * float(seed % 97)
+        m = torch.stack([base * (k + 1) for k in range(7)], dim=1)
         return None, None, m.float(), None
 
 
-def _worker(rank, world, port, X, out_dir):
+PIX = 8 * 8
+
+
+def _worker(rank, world, port, X, out_dir, bs):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = driver.run_dataset(_FakeCodec(2), X, 0.01, its=3, rank=rank, world=world, dist=dist)
+    res = driver.run_dataset(_FakeCodec(1 + rank), X, 0.01, its=3, seed=5, rank=rank, world=world, dist=dist)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_run_and_gather_gloo_world2(tmp_path, monkeypatch):
+@pytest.mark.parametrize("N,bs", [(7, 4), (11, 3)])
+def test_sharded_run_and_gather_gloo_world2(tmp_path, monkeypatch, N, bs):
+    """Sharded (2 ranks, different chunk sizes) == single process, including several RAGGED reference
+    batches (N=11 in batches of 3: 3,3,3,2 -- every batch deals one rank an extra image)."""
     import torch.multiprocessing as mp
-    monkeypatch.setattr(driver, "eval_batch_num_pixels", 4 * 8 * 8)      # reference batch = 4 images
-    # (the monkeypatch does not reach spawned workers: pass sizes that give the same batching)
-    X = np.random.RandomState(0).rand(7, 8, 8, 3).astype(np.float32)
-    single = driver.run_dataset(_FakeCodec(3), X, 0.01, its=3)
+    monkeypatch.setattr(driver, "eval_batch_num_pixels", bs * PIX)
+    # (the monkeypatch does not reach spawned workers: _worker_patched sets the same value there)
+    X = np.random.RandomState(0).rand(N, 8, 8, 3).astype(np.float32)
+    single = driver.run_dataset(_FakeCodec(3), X, 0.01, its=3, seed=5)
     assert np.isfinite(single["psnr"]).all()
-    # loss_scale follows the reference batch the image belongs to: 1/4 for 0..3, 1/3 for 4..6
-    assert np.allclose(single["mse"] - X.mean((1, 2, 3)), [0.25] * 4 + [1 / 3] * 3, atol=1e-6)
-    port = 29500 + (os.getpid() % 2000)
+    if (N, bs) == (7, 4):
+        # loss_scale follows the reference batch (1/4 for 0..3, 1/3 for 4..6), the image id its position
+        # in that batch, the seed the batch number (seed + 1000003 * b_i)
+        exp = X.mean((1, 2, 3)) + np.array([0.25] * 4 + [1 / 3] * 3) + 1e-3 * np.array([0, 1, 2, 3, 0, 1, 2]) \
+            + 1e-5 * np.array([5 % 97] * 4 + [(5 + 1000003) % 97] * 3)
+        assert np.allclose(single["mse"], exp, atol=1e-6)
+    port = 29500 + (os.getpid() % 2000) + N
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker_patched, args=(r, 2, port, X, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_worker_patched, args=(r, 2, port, X, str(tmp_path), bs)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -197,10 +215,23 @@ def test_sharded_run_and_gather_gloo_world2(tmp_path, monkeypatch):
             assert np.allclose(got[k], single[k], atol=1e-6), (r, k)
 
 
-def _worker_patched(rank, world, port, X, out_dir):
+def test_shard_counts_balanced_and_gather_sized_from_them():
+    """Tecnick = 100 images in reference batches of 7.  A fixed round-robin start
+    gave rank 0 15 images on 8 GPUs (and 57 of 100 on 2) against a gather buffer of ceil(N/world)+1;
+    the start rank now rotates with the batch number and the buffer is sized from the real counts."""
+    for N, bs, world in [(100, 7, 8), (100, 7, 2), (40, 7, 4), (24, 25, 8), (11, 3, 2)]:
+        batches = driver.reference_batches(N, bs)
+        counts = [sum(len(driver.shard_batch(b, r, world, i)) for i, b in enumerate(batches)) for r in range(world)]
+        assert sum(counts) == N
+        assert max(counts) - min(counts) <= 1 + (N % bs != 0), (N, bs, world, counts)
+        seen = sorted(i for k, b in enumerate(batches) for r in range(world) for i in driver.shard_batch(b, r, world, k))
+        assert seen == list(range(N))
+
+
+def _worker_patched(rank, world, port, X, out_dir, bs):
     sys.path.insert(0, ROOT)
     import sga_amd  # noqa: F401
     from sga_amd import driver as d
-    d.eval_batch_num_pixels = 4 * 8 * 8
+    d.eval_batch_num_pixels = bs * PIX
     globals()["driver"] = d
-    _worker(rank, world, port, X, out_dir)
+    _worker(rank, world, port, X, out_dir, bs)

@@ -109,7 +109,8 @@ def raw_variables(w, C, bb=False):
         t[f"entropy_bottleneck/bias_{k}"] = w[f"eb.b{k}"]
         if k < 3:
             t[f"entropy_bottleneck/factor_{k}"] = np.arctanh(w[f"eb.f{k}"].astype(np.float64))
-    t["entropy_bottleneck/quantiles"] = np.zeros((C, 1, 3), np.float32)
+    med = w.get("eb.medians", np.zeros(C, np.float32))
+    t["entropy_bottleneck/quantiles"] = np.stack([med - 9.0, med, med + 9.0], -1).reshape(C, 1, 3).astype(np.float32)
     t["analysis_transform/layer_0/bias/Adam"] = np.zeros(C, np.float32)      # optimizer slot: ignored
     return t
 
@@ -161,3 +162,15 @@ def test_npz_weights(tmp_path):
     np.savez(tmp_path / "w.npz", **w)
     got = tfc.load_effective_weights(str(tmp_path / "w.npz"), C)
     assert all(np.array_equal(got[k], w[k]) for k in w)
+
+
+def test_medians_come_from_quantiles():
+    """tfc 1.3: medians = quantiles[:, 0, 1]; mbt2018.py:69 / map.py:83 round z around them."""
+    C = 64
+    w = sga_amd.make_synthetic_weights(C, seed=3)
+    w["eb.medians"] = np.linspace(-0.4, 0.45, C).astype(np.float32)
+    t = {k: np.asarray(v, np.float32) for k, v in raw_variables(w, C).items()}
+    got = tfc.effective_weights_from_tensors(t, C)
+    assert np.array_equal(got["eb.medians"], w["eb.medians"])
+    del t["entropy_bottleneck/quantiles"]            # e.g. the bits-back prior: no medians, no error
+    assert "eb.medians" not in tfc.effective_weights_from_tensors(t, C)

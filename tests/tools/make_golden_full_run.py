@@ -1,0 +1,69 @@
+"""Golden vectors for the north-star acceptance test (sga.py:210-247: the COMPLETE 2000-step run).
+
+Runs the CPU oracle (`SGAOracle.run`: encode, 2000 x (SGA sample, forward, backward, Adam), round,
+evaluate) on a fixed synthetic batch for several Philox seeds and stores the per-image end metrics.
+`tests/test_gpu_acceptance.py` runs the HIP path on the same inputs and seeds and asserts the
+north-star tolerance (|mean d est_bpp| <= 1e-3, |mean d PSNR| <= 0.01 dB) on the means over
+images x seeds, with the measured spread stated next to it.
+
+The trajectories are chaotic in the last float32 bits (a rounding difference flips a floor/ceil
+decision, after which the two runs are different samples of the same stochastic optimiser), so the
+criterion is statistical: this script also records the oracle's own seed-to-seed spread.
+
+    python tests/tools/make_golden_full_run.py            # ~8 min on 4 cores
+"""
+import json
+import os
+import sys
+import time
+from multiprocessing import Pool
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden", "full_run_oracle.json")
+
+CFG = dict(C=64, B=4, H=64, W=64, its=2000, lmbda=0.01, x_seed=6, weight_seed=0, seeds=list(range(32)))
+
+
+def make_inputs(cfg):
+    import numpy as np
+    return np.random.RandomState(cfg["x_seed"]).rand(cfg["B"], cfg["H"], cfg["W"], 3).astype(np.float32)
+
+
+def one_seed(seed):
+    import numpy as np
+    import torch
+    torch.set_num_threads(1)
+    import sga_amd
+    from oracle.sga_oracle import SGAOracle
+    w = sga_amd.make_synthetic_weights(CFG["C"], seed=CFG["weight_seed"])
+    x = make_inputs(CFG)
+    t = time.time()
+    y_hat, z_hat, m, _ = SGAOracle(w).run(x, CFG["lmbda"], its=CFG["its"], seed=seed)
+    return dict(seed=seed, seconds=time.time() - t,
+                est_bpp=m["est_bpp"].astype(np.float64).tolist(), psnr=m["psnr"].astype(np.float64).tolist(),
+                est_y_bpp=m["est_y_bpp"].astype(np.float64).tolist(),
+                est_z_bpp=m["est_z_bpp"].astype(np.float64).tolist(), mse=m["mse"].astype(np.float64).tolist(),
+                y_hat_sum=float(np.abs(y_hat).sum()), z_hat_sum=float(np.abs(z_hat).sum()))
+
+
+def main():
+    import numpy as np
+    nproc = int(os.environ.get("NPROC", 3))
+    with Pool(nproc) as pool:
+        runs = pool.map(one_seed, CFG["seeds"])
+    bpp = np.array([r["est_bpp"] for r in runs])     # [seed, image]
+    psnr = np.array([r["psnr"] for r in runs])
+    out = dict(config=CFG, runs=runs,
+               oracle_seed_spread=dict(est_bpp_std_per_image=bpp.std(0, ddof=1).tolist(),
+                                       psnr_std_per_image=psnr.std(0, ddof=1).tolist(),
+                                       est_bpp_mean=float(bpp.mean()), psnr_mean=float(psnr.mean())),
+               note="oracle = oracle/sga_oracle.py (PyTorch CPU f32, Philox noise); inputs = "
+                    "RandomState(x_seed).rand(B,H,W,3) float32; weights = make_synthetic_weights(C, weight_seed)")
+    with open(OUT, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()
