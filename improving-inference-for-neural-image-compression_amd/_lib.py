@@ -88,6 +88,7 @@ SYMBOLS["sga_bb_run"] = (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _I, _D, _D, _D, _I
 SYMBOLS["sga_bb_eval"] = (_I, [_P, _P, _I, _I, _I, _P, _P, _P, C.c_uint64, _P, _P])
 SYMBOLS["sga_op_factorized_density"] = (_I, [_P, _P, _I64, _P, _P, _P])
 SYMBOLS["sga_set_relaxation"] = (_I, [_P, _I, _I])
+SYMBOLS["sga_op_rate_terms"] = (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P])
 SYMBOLS["sga_set_image_ids"] = (_I, [_P, C.POINTER(C.c_int32), _I])
 PRECISIONS = {"default": 0, "f32": 1, "bf16x3": 2}
 RELAXATIONS = {"sga": 0, "danneal": 1, "unoise": 2, "ste": 3, "none": 4}

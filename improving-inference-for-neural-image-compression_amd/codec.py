@@ -465,6 +465,22 @@ class SGACodec:
         return tuple(outs)
 
 
+    def rate_terms(self, y_tilde, z_tilde, ms, H, W, loss_scale=None):
+        """The step's own entropy-model kernels on fed intermediates (sga.py:100-104,126-146):
+        -> dict(g_yt, g_ms, g_zt, est_y_bpp[B], est_z_bpp[B])."""
+        yt, zt, ms = self._t(y_tilde), self._t(z_tilde), self._t(ms)
+        B = yt.shape[0]
+        if loss_scale is None:
+            loss_scale = 1.0 / B
+        g_yt, g_ms, g_zt, met = torch.empty_like(yt), torch.empty_like(ms), torch.empty_like(zt), self._empty(B, 7)
+        s = self._enter()
+        self._chk(self.lib.sga_op_rate_terms(self.handle, _ptr(yt), _ptr(zt), _ptr(ms), B, int(H), int(W),
+                                             float(loss_scale), _ptr(g_yt), _ptr(g_ms), _ptr(g_zt), _ptr(met), s),
+                  "sga_op_rate_terms")
+        self._exit()
+        return dict(g_yt=g_yt, g_ms=g_ms, g_zt=g_zt, est_y_bpp=met[:, 5], est_z_bpp=met[:, 6])
+
+
 def metrics_to_dict(met) -> dict:
     """[B,7] metrics tensor -> dict keyed like sga.py:183 eval_fields (numpy arrays)."""
     m = met.detach().cpu().numpy()

@@ -1429,6 +1429,32 @@ int sga_op_gaussian_likelihood(sga_handle* h, const float* y, const float* mu,
   return SGA_OK;
 }
 
+// The rate half of the graph with fed intermediates (the reference can feed y_tilde / z_tilde and
+// fetch any tensor, sga.py:219-225): exactly the kernels the SGA step launches for sga.py:100-104
+// and :126-146 -- factorized mass of z_tilde and box-Gaussian mass of y_tilde under (mu |
+// sigma_raw) = ms, both with lower_bound and its gradient rule (math_ops.py:63-76) -- and their
+// gradients of train_bpp = loss_scale * sum_b (y_bpp + z_bpp).
+int sga_op_rate_terms(sga_handle* h, const float* y_tilde, const float* z_tilde, const float* ms, int B,
+                      int H, int W, float loss_scale, float* g_yt, float* g_ms, float* g_zt,
+                      float* metrics, void* stream) {
+  if (!h || !y_tilde || !z_tilde || !ms) return SGA_ERR_BAD_ARG;
+  SGACHK(check_shape(h, B, H, W));
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(B, H, W);
+  const float il = inv_ln2_hw(g);
+  HIPCHK(h, launch_set_ctx(h->ctx, 0, 0, 1.f, 0.f, 0.f, loss_scale, 0, st));
+  HIPCHK(h, launch_fill((float*)h->sums, 0.f, (int64_t)(sizeof(ImgSums) / sizeof(float)) * B, st));
+  HIPCHK(h, launch_factorized(z_tilde, h->eb_packed, h->ctx, B, g.zh * g.zw, h->C, il, h->sums, g_zt, nullptr,
+                              nullptr, st));
+  HIPCHK(h, launch_gaussian(y_tilde, ms, h->ctx, B, g.yh, g.yw, g.hsh, g.hsw, h->C, il, h->sums, g_yt, g_ms, st));
+  if (metrics) {   // [B][7] in the order of sga.py:183; only est_bpp / est_y_bpp / est_z_bpp are meaningful
+    HIPCHK(h, launch_finalize_eval(h->sums, B, H, W, metrics, st));
+  } else {
+    HIPCHK(h, launch_fill((float*)h->sums, 0.f, (int64_t)(sizeof(ImgSums) / sizeof(float)) * B, st));
+  }
+  return SGA_OK;
+}
+
 int sga_set_relaxation(sga_handle* h, int relaxation, int schedule) {
   if (!h || relaxation < 0 || relaxation > SGA_RELAX_NONE || schedule < 0 || schedule > SGA_SCHED_EXP)
     return SGA_ERR_BAD_ARG;

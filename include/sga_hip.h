@@ -233,6 +233,17 @@ int sga_op_gaussian_likelihood(sga_handle* h, const float* y, const float* mu,
                                float* p, float* dp_dy, float* dp_dmu, float* dp_dsraw,
                                void* stream);
 
+/* The rate half of the graph with fed intermediates (the reference can feed y_tilde / z_tilde and
+ * fetch any tensor, sga.py:219-225): the very kernels the SGA step launches for sga.py:100-104 and
+ * :126-146 -- factorized mass of z_tilde [B,zh,zw,C], box-Gaussian mass of y_tilde [B,yh,yw,C] under
+ * ms = (mu | sigma_raw) [B,4zh,4zw,2C] (cropped to the y grid, sga.py:126-128), both through
+ * lower_bound with its gradient rule (math_ops.py:63-76) -- and the gradients of
+ * train_bpp = loss_scale * sum_b (y_bpp[b] + z_bpp[b]) w.r.t. y_tilde, ms and z_tilde.
+ * metrics[B][7]: est_bpp, est_y_bpp, est_z_bpp filled (fields 4..6).  Any output may be NULL. */
+int sga_op_rate_terms(sga_handle* h, const float* y_tilde, const float* z_tilde, const float* ms, int B,
+                      int H, int W, float loss_scale, float* g_yt, float* g_ms, float* g_zt,
+                      float* metrics, void* stream);
+
 /* ---- measurement: per-kernel hipEvent timing of the convolution launches -------------------
  * Between sga_profile_begin and sga_profile_end every MFMA convolution launch issued through
  * this handle is bracketed by a hipEvent pair on its own stream (sga_run then launches eagerly

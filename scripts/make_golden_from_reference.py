@@ -11,6 +11,11 @@ the GPU box.  Fixtures are data (inputs + the reference's outputs); no reference
   fixture pins the reference's formula (the |x-mu| tail trick, the +-0.5 box, the division by
   sigma), not TensorFlow's erfc rounding.
 
+* learned_prior.py / math_ops.py also start with `import tensorflow`; the class `BMSHJ2018Prior`
+  (the CDF network `_logits_cdf`, `cdf`, the closed-form `cdf_pdf`) and the gradient functions of
+  `lower_bound` / `upper_bound` are executed unmodified against a small numpy-backed stand-in for the
+  TensorFlow names they use (matmul, softplus, tanh, sigmoid, transpose, reshape, logical_or, cast).
+
     python scripts/make_golden_from_reference.py
 """
 import json
@@ -76,10 +81,161 @@ def utils_fixtures():
         json.dump([dict(args=c, runname=ns["get_runname"](c, prefix="mbt2018")) for c in cases], f, indent=1)
 
 
+# ---------------------------------------------------------------------------------------------
+# learned_prior.py / math_ops.py against a numpy-backed `tf` namespace
+# ---------------------------------------------------------------------------------------------
+class _Shape:
+    """what `Tensor.get_shape()` must offer to learned_prior.py:137-142"""
+    def __init__(self, shp):
+        self._s, self.ndims = tuple(int(d) for d in shp), len(shp)
+
+    def __getitem__(self, i):
+        return self._s[i]
+
+
+class _T(np.ndarray):
+    def get_shape(self):
+        return _Shape(self.shape)
+
+
+def _t(a):
+    return np.asarray(a, dtype=np.float64).view(_T)
+
+
+def _numpy_tf(injected):
+    """The handful of TensorFlow names the prior's CDF network and the bound gradients use, backed by
+    numpy float64.  Variables come from `injected` (name -> array) instead of the initialisers."""
+    import types
+
+    class Model:                                  # stands in for tf.keras.Model
+        dtype = "float64"
+
+        def __init__(self, **kwargs):
+            pass
+
+        def add_weight(self, name, dtype=None, shape=None, initializer=None):
+            v = _t(injected[name])
+            assert tuple(v.shape) == tuple(shape), (name, v.shape, shape)
+            return v
+
+    def softplus(x):
+        return _t(np.log1p(np.exp(-np.abs(x))) + np.maximum(x, 0))
+
+    ns = types.SimpleNamespace
+    init = ns(constant=lambda v: None, random_uniform=lambda a, b: None, zeros=lambda: None)
+    return ns(
+        keras=ns(Model=Model), initializers=init,
+        nn=ns(softplus=softplus, sigmoid=lambda x: _t(1.0 / (1.0 + np.exp(-x)))),
+        math=ns(tanh=lambda x: _t(np.tanh(x))),
+        linalg=ns(matmul=lambda a, b: _t(np.matmul(a, b))),
+        matmul=lambda a, b: _t(np.matmul(a, b)),
+        executing_eagerly=lambda: False, stop_gradient=lambda x: x,
+        transpose=lambda a, perm: _t(np.transpose(a, perm)), shape=lambda a: tuple(a.shape),
+        reshape=lambda a, shp: _t(np.reshape(a, shp)), expand_dims=lambda a, ax: _t(np.expand_dims(a, ax)),
+        RegisterGradient=lambda name: (lambda f: f),
+        logical_or=np.logical_or, cast=lambda x, dt: np.asarray(x).astype(dt),
+    )
+
+
+def _exec_reference_defs(fname, names, ns):
+    """exec the named top-level class / function definitions of /root/reference/<fname>, unmodified."""
+    import ast
+    with open(os.path.join(REF, fname)) as f:
+        tree = ast.parse(f.read())
+    keep = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    assert {n.name for n in keep} == set(names), ({n.name for n in keep}, names)
+    exec(compile(ast.Module(body=keep, type_ignores=[]), f"reference:{fname}", "exec"), ns)
+    return ns
+
+
+def prior_fixtures():
+    """learned_prior.py:78-121 (`_logits_cdf`), :123-162 (`cdf`), :263-360 (closed-form `cdf_pdf`) and
+    math_ops.py:45-76 (`_upper_bound_grad`, `_lower_bound_grad`), executed as they stand.  Pins the
+    FORMULAS (layer order, softplus'd matrices, the `x + tanh(factor) * tanh(x)` nonlinearity, the
+    Jacobian chain, the pass-through rule of the bounds); float64 numpy arithmetic, so not TF's
+    float32 rounding."""
+    C, dims = 64, (3, 3, 3)
+    rng = np.random.RandomState(2024)
+    d = (1,) + dims + (1,)
+    scale = 10.0 ** (1.0 / 4.0)
+    raw = {}
+    for i in range(4):
+        raw[f"matrix_{i}"] = np.log(np.expm1(1 / scale / d[i + 1])) + 0.3 * rng.standard_normal((C, d[i + 1], d[i]))
+        raw[f"bias_{i}"] = rng.uniform(-0.5, 0.5, (C, d[i + 1], 1))
+        if i < 3:
+            raw[f"factor_{i}"] = 0.5 * rng.standard_normal((C, d[i + 1], 1))
+    tf = _numpy_tf(raw)
+    ns = _exec_reference_defs("learned_prior.py", ["BMSHJ2018Prior"], {"tf": tf, "np": np, "math_ops": None})
+    prior = ns["BMSHJ2018Prior"](C, dims=dims, init_scale=10.0)
+    out = {"channels": np.int64(C)}
+    # The HIP path takes float32 EFFECTIVE parameters (softplus'd / tanh'd, include/sga_hip.h): let the
+    # reference evaluate exactly those values (graph mode reads self._matrices / self._factors)
+    for i in range(4):
+        m32 = np.asarray(prior._matrices[i], np.float32)
+        prior._matrices[i] = _t(m32)
+        out[f"eb.m{i}"] = m32
+        b32 = np.asarray(prior._biases[i], np.float32)
+        prior._biases[i] = _t(b32)
+        out[f"eb.b{i}"] = b32
+        if i < 3:
+            f32 = np.asarray(prior._factors[i], np.float32)
+            prior._factors[i] = _t(f32)
+            out[f"eb.f{i}"] = f32
+        out[f"raw_matrix_{i}"] = raw[f"matrix_{i}"]
+    # inputs [N, C] float32-representable: bulk, integers and half-integers, far tails
+    v = np.concatenate([rng.standard_normal((80, C)) * 4.0, np.round(rng.standard_normal((8, C)) * 3.0),
+                        np.round(rng.standard_normal((4, C)) * 3.0) + 0.5,
+                        np.full((1, C), -30.0), np.full((1, C), 30.0), np.full((1, C), 12.0), np.zeros((1, C)),
+                        np.full((1, C), -400.0), np.full((1, C), 400.0), np.full((1, C), -150.0), np.full((1, C), 150.0)])
+    v = v.astype(np.float32).astype(np.float64)
+    out["v"] = v.astype(np.float32)
+
+    def logits(x):                                   # learned_prior.py:96-121 through the reshapes of :144-150
+        order = [1, 0]
+        t = tf.reshape(tf.transpose(_t(x), order), (C, 1, -1))
+        return np.asarray(tf.transpose(tf.reshape(prior._logits_cdf(t, stop_gradient=False), (C, -1)), order))
+
+    out["logits_cdf"] = logits(v)
+    out["cdf"] = np.asarray(prior.cdf(_t(v), stop_gradient=False))
+    cdf2, pdf = prior.cdf_pdf(_t(v), stop_gradient=False)
+    out["cdf_closed_form"], out["pdf"] = np.asarray(cdf2), np.asarray(pdf)
+    # box mass of tfc EntropyBottleneck._likelihood (sga.py:101) FROM THE REFERENCE'S LOGITS: the sign
+    # trick itself is tfc's (un-vendored; SURVEY a8), the logits and the plain CDF difference are the reference's
+    lo, up = logits(v - 0.5), logits(v + 0.5)
+    sg = -np.sign(lo + up)
+    sig = lambda t: 1.0 / (1.0 + np.exp(-t))
+    out["mass_sign_trick"] = np.abs(sig(sg * up) - sig(sg * lo))
+    out["mass_cdf_difference"] = np.asarray(prior.cdf(_t(v + 0.5), False)) - np.asarray(prior.cdf(_t(v - 0.5), False))
+    out["dmass_dv"] = np.asarray(prior.cdf_pdf(_t(v + 0.5))[1]) - np.asarray(prior.cdf_pdf(_t(v - 0.5))[1])
+    # derivative of the density (bb_sga.py differentiates through learned_prior.pdf): Richardson-
+    # extrapolated central differences of the reference's closed-form pdf (O(h^4), float64)
+    pdf_at = lambda x: np.asarray(prior.cdf_pdf(_t(x))[1])
+    h = 1e-2
+    d1 = (pdf_at(v + h) - pdf_at(v - h)) / (2 * h)
+    d2 = (pdf_at(v + h / 2) - pdf_at(v - h / 2)) / h
+    out["dpdf_dv_fd"] = (4 * d2 - d1) / 3
+    # ---- math_ops.py:45-76: the bounds' pass-through rule, every (side of the bound) x (gradient sign)
+    import types
+    ns2 = _exec_reference_defs("math_ops.py", ["_lower_bound_grad", "_upper_bound_grad"], {"tf": tf})
+    x = np.array([0.05, 0.11, 0.5, 0.05, 0.11, 0.5, 0.05, 0.11, 0.5], np.float32)
+    g = np.array([-2.0, -2.0, -2.0, 0.0, 0.0, 0.0, 3.0, 3.0, 3.0], np.float32)
+    bound = np.float32(0.11)
+    out["bound_x"], out["bound_g"], out["bound"] = x, g, bound
+    out["lower_bound_grad"] = ns2["_lower_bound_grad"](types.SimpleNamespace(inputs=(x, bound)), g)[0]
+    out["upper_bound_grad"] = ns2["_upper_bound_grad"](types.SimpleNamespace(inputs=(x, bound)), g)[0]
+    np.savez_compressed(os.path.join(OUT, "prior_reference.npz"), **out)
+    # self-checks of the fixture: the two routes to the CDF agree, the closed-form pdf is its derivative
+    assert np.allclose(out["cdf"], out["cdf_closed_form"], rtol=0, atol=1e-15)
+    cdf_at = lambda x: np.asarray(prior.cdf(_t(x), False))
+    fd = (cdf_at(v + 1e-5) - cdf_at(v - 1e-5)) / 2e-5
+    assert np.allclose(fd, out["pdf"], rtol=1e-6, atol=1e-10), np.abs(fd - out["pdf"]).max()
+
+
 def main():
     sys.path.insert(0, REF)
     os.makedirs(OUT, exist_ok=True)
     utils_fixtures()
+    prior_fixtures()
     import adam as ref_adam          # /root/reference/adam.py
     import configs as ref_configs    # /root/reference/configs.py
     os.makedirs(OUT, exist_ok=True)

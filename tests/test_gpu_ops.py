@@ -211,6 +211,114 @@ def test_gaussian_likelihood_reference_fixture():
     assert np.allclose(p, want, rtol=2e-4, atol=1e-7), float(np.abs(p - want).max())
 
 
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _prior_fixture_codec():
+    """Codec + float64 oracle whose factorized prior is the one of tests/golden/prior_reference.npz."""
+    from sga_amd.codec import SGACodec
+    if "prior_fx" not in _CODECS:
+        fx = np.load(os.path.join(GOLDEN, "prior_reference.npz"))
+        C = int(fx["channels"])
+        w = dict(sga_amd.make_synthetic_weights(C, seed=0))
+        for k in fx.files:
+            if k.startswith("eb."):
+                w[k] = fx[k]
+        _CODECS["prior_fx"] = (SGACodec(w, C, max_batch=4, max_height=96, max_width=96), SGAOracle(w, dtype=torch.float64), fx)
+    return _CODECS["prior_fx"]
+
+
+def test_factorized_prior_vs_reference_executed_fixture(gpu_out_dir):
+    """sga_op_factorized_likelihood / sga_op_factorized_density (the kernels of sga.py:101 and
+    bb_sga.py:109) against values produced by learned_prior.py's own code (`_logits_cdf`, `cdf_pdf`;
+    tests/golden/prior_reference.npz).  Float32 kernels vs float64 reference: relative 2e-5 where the
+    value is not in the far tail, absolute otherwise."""
+    codec, _, fx = _prior_fixture_codec()
+    v = fx["v"]
+    p, dp = (t.cpu().numpy().astype(np.float64) for t in codec.factorized_likelihood(v))
+    q, dq = (t.cpu().numpy().astype(np.float64) for t in codec.factorized_density(v))
+    errs = dict(mass=float(np.abs(p - fx["mass_sign_trick"]).max() / fx["mass_sign_trick"].max()),
+                dmass=float(np.abs(dp - fx["dmass_dv"]).max() / np.abs(fx["dmass_dv"]).max()),
+                pdf=float(np.abs(q - fx["pdf"]).max() / fx["pdf"].max()),
+                dpdf=float(np.abs(dq - fx["dpdf_dv_fd"]).max() / np.abs(fx["dpdf_dv_fd"]).max()))
+    report(gpu_out_dir, "prior_reference_fixture", **errs)
+    assert np.allclose(p, fx["mass_sign_trick"], rtol=2e-5, atol=2e-8), errs
+    assert np.allclose(dp, fx["dmass_dv"], rtol=1e-4, atol=2e-7), errs
+    assert np.allclose(q, fx["pdf"], rtol=2e-5, atol=2e-8), errs
+    assert np.allclose(dq, fx["dpdf_dv_fd"], rtol=2e-4, atol=2e-7), errs
+    # far tails keep digits thanks to the sign trick (a plain sigmoid difference is 0 in float32 there)
+    tail = fx["mass_sign_trick"] < 1e-9
+    tail &= fx["mass_sign_trick"] > 1e-30
+    assert tail.sum() > 50 and (p[tail] > 0).all() and np.allclose(p[tail], fx["mass_sign_trick"][tail], rtol=1e-3, atol=0)
+
+
+def test_lower_bound_branches_in_the_step_kernels(gpu_out_dir):
+    """math_ops.py:63-76 inside the kernels of the SGA step (k_gaussian / k_factorized, driven through
+    sga_op_rate_terms with fed intermediates): every combination of
+      sigma below / above scale_bound = 0.11 (sga.py:129)   x   sign of the gradient reaching sigma,
+      p below / above likelihood_bound = 1e-9 (sga.py:134-136, 102-104),
+    against float64 autograd of the oracle, whose bound gradient is pinned to the reference-executed
+    fixture (tests/test_oracle.py)."""
+    codec, o64, _ = _prior_fixture_codec()
+    C, B, H, W = codec.C, 1, 64, 64
+    yh, yw, zh, zw = codec.latent_shape(H, W)
+    hs, ws = 4 * zh, 4 * zw
+    rng = np.random.RandomState(7)
+    # element classes along the channel axis; (|y - mu|, sigma) chosen well away from every threshold
+    cases = [("sig_lo_g_pos", 0.00, 0.05),    # sigma < 0.11, p falls when sigma grows  -> gradient BLOCKED
+             ("sig_lo_g_neg", 0.70, 0.05),    # sigma < 0.11, p grows with sigma        -> passes, chain factor = sigma
+             ("sig_hi_g_pos", 0.10, 0.50),    # sigma >= 0.11, either sign passes
+             ("sig_hi_g_neg", 1.50, 0.50),
+             ("p_below_bound", 3.60, 0.50),   # p ~ 2.8e-10 < 1e-9: -log2 uses 1e-9, gradient passes (it is < 0)
+             ("p_zero", 6.00, 0.11)]          # p underflows to 0
+    k = np.arange(C) % len(cases)
+    dist = np.array([c[1] for c in cases], np.float32)[k]
+    sigma = np.array([c[2] for c in cases], np.float32)[k]
+    mu = rng.standard_normal((B, hs, ws, C)).astype(np.float32)
+    sraw = np.broadcast_to(np.log(sigma), (B, hs, ws, C)).astype(np.float32).copy()
+    ms = np.concatenate([mu, sraw], -1)
+    sgn = np.where(rng.rand(B, yh, yw, C) < 0.5, -1.0, 1.0).astype(np.float32)
+    yt = (mu[:, :yh, :yw] + sgn * dist).astype(np.float32)
+    # z_tilde: bulk plus far-tail values where the factorized mass is below 1e-9
+    zt = (rng.standard_normal((B, zh, zw, C)) * 3).astype(np.float32)
+    zt[..., ::5] = np.where(rng.rand(B, zh, zw, len(range(0, C, 5))) < 0.5, -400.0, 400.0)
+    got = codec.rate_terms(yt, zt, ms, H, W, loss_scale=1.0)
+    # float64 oracle of the same sub-graph (sga.py:100-104, 126-146)
+    from oracle.sga_oracle import LIKELIHOOD_BOUND
+    ytt = torch.tensor(yt, dtype=torch.float64, requires_grad=True)
+    ztt = torch.tensor(zt, dtype=torch.float64, requires_grad=True)
+    mst = torch.tensor(ms, dtype=torch.float64, requires_grad=True)
+    mu_t, sr_t = mst[..., :C][:, :yh, :yw], mst[..., C:][:, :yh, :yw]
+    p_y_raw = o64.gauss_likelihood(ytt, mu_t, torch.exp(sr_t))
+    p_z_raw = o64.eb_likelihood(ztt)
+    p_y, p_z = lower_bound(p_y_raw, LIKELIHOOD_BOUND), lower_bound(p_z_raw, LIKELIHOOD_BOUND)
+    den = np.log(2.0) * H * W
+    y_bpp, z_bpp = -torch.log(p_y).sum() / den, -torch.log(p_z).sum() / den
+    g_yt, g_ms, g_zt = torch.autograd.grad(y_bpp + z_bpp, [ytt, mst, ztt])
+    # the crafted classes really are where they are meant to be
+    pr = p_y_raw.detach().numpy()
+    assert (pr[..., k == 4] < 3e-10).all() and (pr[..., k == 4] > 0).all() and (pr[..., k == 5] < 1e-30).all()
+    assert (p_z_raw.detach().numpy()[..., ::5] < 1e-12).all()
+    gs = g_ms[..., C:][:, :yh, :yw].numpy()
+    assert (gs[..., k == 0] == 0).all()                                  # blocked
+    assert (gs[..., k == 1] < 0).all() and (gs[..., k == 2] > 0).all() and (gs[..., k == 3] < 0).all()
+    assert (gs[..., k == 4] != 0).all()                                   # bounded p still has a gradient
+    for name, a, b_, tol in (("g_yt", got["g_yt"], g_yt, 2e-4), ("g_ms", got["g_ms"], g_ms, 2e-4),
+                             ("g_zt", got["g_zt"], g_zt, 1e-3)):     # deep-tail dp/dv in float32: 4e-4
+        a, b_ = a.cpu().numpy().astype(np.float64), b_.numpy()
+        for ci, c in enumerate(cases if name != "g_zt" else []):
+            sel = (k == ci)
+            parts = [a[..., :C][..., sel], b_[..., :C][..., sel]] if name == "g_ms" else [a[..., sel], b_[..., sel]]
+            report(gpu_out_dir, "lower_bound_branch", grad=name, case=c[0], rel_err=rel_err(*parts))
+        scale = np.abs(b_).max()
+        assert np.allclose(a, b_, rtol=tol, atol=tol * 1e-3 * scale), (name, where_bad(a, b_, tol))
+    # exact zeros where the rule blocks, also in float32
+    a = got["g_ms"].cpu().numpy()[..., C:][:, :yh, :yw]
+    assert (a[..., k == 0] == 0).all()
+    assert np.allclose(got["est_y_bpp"].cpu().numpy(), [float(y_bpp.detach())], rtol=2e-5)
+    assert np.allclose(got["est_z_bpp"].cpu().numpy(), [float(z_bpp.detach())], rtol=2e-5)
+
+
 def test_lower_bound_truth_table():
     """math_ops.py:63-76 (oracle side; the kernels' use of it is covered by step parity)."""
     x = torch.tensor([0.5, 0.5, 2.0, 2.0], requires_grad=True)

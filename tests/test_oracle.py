@@ -137,6 +137,51 @@ def test_lower_bound_truth_table():
     assert gx.tolist() == [0.0, -1.0, 1.0, -1.0]
 
 
+def _prior_fixture_and_oracle(dtype=torch.float64):
+    fx = np.load(os.path.join(GOLDEN, "prior_reference.npz"))
+    w = dict(sga_amd.make_synthetic_weights(int(fx["channels"]), seed=0))
+    for k in ("eb.m0", "eb.m1", "eb.m2", "eb.m3", "eb.b0", "eb.b1", "eb.b2", "eb.b3", "eb.f0", "eb.f1", "eb.f2"):
+        w[k] = fx[k]
+    return fx, SGAOracle(w, dtype=dtype)
+
+
+def test_prior_network_matches_reference_executed_fixture():
+    """tests/golden/prior_reference.npz = learned_prior.py's own `_logits_cdf` / `cdf` / closed-form
+    `cdf_pdf`, executed unmodified on a numpy-backed `tf` (scripts/make_golden_from_reference.py).
+    The oracle's CDF network, box mass and density must reproduce them (float64: to rounding)."""
+    fx, o64 = _prior_fixture_and_oracle()
+    v = torch.tensor(fx["v"], dtype=torch.float64)
+    assert np.allclose(o64.eb_logits_cdf(v).numpy(), fx["logits_cdf"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(torch.sigmoid(o64.eb_logits_cdf(v)).numpy(), fx["cdf"], rtol=0, atol=1e-14)
+    # density (learned_prior.py:164-185 via autograd here, closed form :296-347 in the fixture)
+    assert np.allclose(o64.eb_pdf(v).detach().numpy(), fx["pdf"], rtol=1e-10, atol=1e-16)
+    # box mass: the sign trick (tfc, restated) on the reference's logits == the plain CDF difference
+    # wherever the latter has digits left
+    mass = o64.eb_likelihood(v).numpy()
+    assert np.allclose(mass, fx["mass_sign_trick"], rtol=1e-11, atol=1e-18)
+    ok = fx["mass_cdf_difference"] > 1e-6
+    assert np.allclose(mass[ok], fx["mass_cdf_difference"][ok], rtol=1e-8)
+    # derivatives the gradient path needs: d mass / dv = pdf(v+.5) - pdf(v-.5); d pdf / dv
+    vv = v.clone().requires_grad_(True)
+    (dm,) = torch.autograd.grad(o64.eb_likelihood(vv).sum(), vv)
+    assert np.allclose(dm.numpy(), fx["dmass_dv"], rtol=1e-8, atol=1e-14)
+    vv = v.clone().requires_grad_(True)
+    (dp,) = torch.autograd.grad(o64.eb_pdf(vv).sum(), vv)
+    assert np.allclose(dp.numpy(), fx["dpdf_dv_fd"], rtol=2e-5, atol=1e-9)      # fixture side is a finite difference
+
+
+def test_bound_gradients_match_reference_executed_fixture():
+    """math_ops.py:45-76 executed unmodified: every (side of the bound) x (gradient sign)."""
+    fx = np.load(os.path.join(GOLDEN, "prior_reference.npz"))
+    x = torch.tensor(fx["bound_x"], requires_grad=True)
+    (gx,) = torch.autograd.grad(lower_bound(x, float(fx["bound"])), x, torch.tensor(fx["bound_g"]))
+    assert np.array_equal(gx.numpy(), fx["lower_bound_grad"])
+    # the fixture itself: blocked only when x < bound and the gradient is >= 0 (equality passes)
+    want = [-2, -2, -2, 0, 0, 0, 0, 3, 3]
+    assert fx["lower_bound_grad"].tolist() == want
+    assert fx["upper_bound_grad"].tolist() == [-2, -2, 0, 0, 0, 0, 3, 3, 3]      # mirror rule (x <= b or g > 0)
+
+
 def test_likelihood_masses_sum_to_one(orc):
     o32, o64, _ = orc
     ks = torch.arange(-400, 401, dtype=torch.float64)
