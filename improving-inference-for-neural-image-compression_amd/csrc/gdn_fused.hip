@@ -1,0 +1,354 @@
+// GDN / IGDN (tfc.GDN, nn_models.py:17-25,51-59) and the IGDN data-gradient as ONE tile kernel that
+// touches every HBM byte once and absorbs the work of its neighbours:
+//
+//   prologue   T [BM pixels x C] =  sum of the producing convolution's split-K partial slabs (+ bias)
+//                                   (what splitk_reduce_kernel + a re-read used to do), or
+//                                   a fresh 5x5/2 convolution of the 3-channel gradient image
+//                                   (the data-gradient of the C->3 synthesis layer, nn_models.py:63),
+//                                   computed on the matrix pipe straight into the tile;
+//   operand    A = T^2 (forward)  or  g*u/s (backward), kept RESIDENT in LDS for the whole C x C
+//              contraction with gamma: no re-staging per K-step, no second read from HBM;
+//   epilogue   forward : n = A.gamma + beta, s = sqrt(n), v = T*s (IGDN) | T/s (GDN)   -> s, v (+ T)
+//              backward: g_u = g*s + u*(A.gamma)                                        -> g_u
+//              from per-thread registers that were filled by the SAME coalesced loads as the tile.
+//
+// A tile is BM consecutive NHWC pixels = one contiguous block of BM*C floats, so all global traffic
+// is linear 16-byte accesses.  The contraction runs on v_mfma_f32_32x32x2_f32 with the K order of
+// conv_mfma.hip (bitwise the same f32 fmaf chain as the stand-alone kernels it replaces).
+//
+// LDS: tile [BM][C+4] (pitch = 4 mod 64 banks: conflict-free ds_read_b128 fragments, conflict-free
+// C-layout scatter) + one K-step of gamma [C][36]; BM = 64, C = 192: 78 KB -> 2 workgroups per CU,
+// so one workgroup's loads/stores overlap the other's MFMAs.
+#include <cstdio>
+#include <cstdlib>
+
+#include "sga_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int LDK = 36;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+
+template <int NC, int WM, int WN, int MODE, int PRO>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs a) {
+  constexpr int C = NC * 32, NT = WM * WN * 64, BM = WM * 32, TN = NC / WN;
+  constexpr int TP = C + 4;                      // tile pitch (floats)
+  constexpr int C4 = C / 4;                      // float4 per tile row
+  constexpr int NF = BM * C4 / NT;               // float4 pieces owned by a thread
+  constexpr int RPP = NT / 8;                    // rows covered by one pass of the K-step loaders
+  constexpr int PB = C / RPP;
+  static_assert(NC % WN == 0 && (BM * C4) % NT == 0 && C % RPP == 0, "tile/loader mismatch");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Tt = smem;                              // [BM][TP]
+  float* Bs = smem + BM * TP;                    // [C][LDK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int chunk = tid & 7, lrow = tid >> 3;
+  const int half = lane >> 5, col = lane & 31, koff = half * 4;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const float* __restrict__ gw = a.w;
+
+  f32x4 rb[PB];
+  auto load_b = [&](const float* w, int kpitch, int k0) {
+#pragma unroll
+    for (int p = 0; p < PB; ++p) rb[p] = ld4(w + (size_t)(p * RPP + lrow) * kpitch + k0 + chunk * 4);
+  };
+  auto store_b = [&]() {
+#pragma unroll
+    for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(&Bs[(p * RPP + lrow) * LDK + chunk * 4]) = rb[p];
+  };
+
+  f32x16 acc[TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tn][r] = 0.f;
+  };
+  // 32 k's of A (rows of `A`, pitch `ap`, starting at float offset k0) against the staged Bs
+  auto mfma_step = [&](const float* A, int ap, int k0) {
+    const int arow = wm * 32 + col;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 af = *reinterpret_cast<const f32x4*>(&A[arow * ap + k0 + q * 8 + koff]);
+      f32x4 bf[TN];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        bf[tn] = *reinterpret_cast<const f32x4*>(&Bs[((wn * TN + tn) * 32 + col) * LDK + q * 8 + koff]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r], bf[tn][r], acc[tn], 0, 0, 0);
+    }
+  };
+  // accumulators -> tile (C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3)+8*(reg>>2)+4*half)
+  auto acc_to_tile = [&]() {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        Tt[(wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * TP + (wn * TN + tn) * 32 + col] = acc[tn][reg];
+  };
+
+  // ---- prologue (b): g = 5x5/2 convolution of the zero-bordered 3-channel image ---------------
+  if constexpr (PRO == GDN_PRO_CONV3) {
+    constexpr int PA = BM / RPP;
+    static_assert(BM % RPP == 0, "conv loader mismatch");
+    float* As = Tt;                              // [BM][LDK], aliases the (not yet filled) tile
+    int a_off[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const long long m = m0 + p * RPP + lrow;
+      a_off[p] = -1;
+      if (m < a.M) {
+        const int j = (int)(m % a.Wg);
+        const long long t = m / a.Wg;
+        const int i = (int)(t % a.Hg), b = (int)(t / a.Hg);
+        a_off[p] = ((b * a.Hp + 2 * i) * a.Wp + 2 * j) * 3;
+      }
+    }
+    zero_acc();
+    f32x4 ra[PA];
+    auto load_a = [&](int step) {
+      // one K-step = kernel rows (2*step, 2*step+1), 16 floats each (5 taps x 3 channels + 1 of slack
+      // that meets a zero weight); row 5 does not exist: its weights are zero, re-read row 4
+      int ky = 2 * step + (chunk >> 2);
+      ky = ky > 4 ? 4 : ky;
+#pragma unroll
+      for (int p = 0; p < PA; ++p) {
+        const bool okp = a_off[p] >= 0;
+        const float* src = a.pad + (size_t)(okp ? a_off[p] : 0) + (size_t)ky * a.Wp * 3 + (chunk & 3) * 4;
+        const f32x2 lo = ld2(src), hi = ld2(src + 2);
+        ra[p] = okp ? f32x4{lo.x, lo.y, hi.x, hi.y} : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    load_a(0);
+    load_b(a.wc, 32, 0);
+#pragma unroll 1
+    for (int step = 0; step < 3; ++step) {
+#pragma unroll
+      for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(&As[(p * RPP + lrow) * LDK + chunk * 4]) = ra[p];
+      store_b();
+      __syncthreads();
+      if (step + 1 < 3) {
+        load_a(step + 1);
+        load_b(a.wc + (size_t)(step + 1) * C * 32, 32, 0);
+      }
+      mfma_step(As, LDK, 0);
+      __syncthreads();
+    }
+    acc_to_tile();                               // g in the tile (As is dead: every wave passed the barrier)
+    __syncthreads();
+  }
+
+  load_b(gw, C, 0);                              // first K-step of gamma: in flight during the fill
+
+  // ---- fill: one coalesced pass over the tile's inputs ----------------------------------------
+  // The tile is the contiguous block [m0*C, (m0+BM)*C): piece f of it sits at float offset 4f.  All
+  // loads are unconditional (pieces past M re-read piece 0 and are discarded by a select) and issued
+  // in groups of G pieces so that a group's loads are in flight together.
+  const long long rows_left = a.M - m0;
+  const int fvalid = rows_left >= BM ? BM * C4 : (int)rows_left * C4;      // pieces f < fvalid are real
+  const float* __restrict__ src0 = a.src ? a.src + (size_t)m0 * C : nullptr;
+  const float* __restrict__ up = (MODE == GDN_IGDN_BWD) ? a.u + (size_t)m0 * C : nullptr;
+  const float* __restrict__ sp = (MODE == GDN_IGDN_BWD) ? a.s + (size_t)m0 * C : nullptr;
+  int smax = a.nsplit[0];
+  if (a.s_out == 2) {
+    smax = max(max(a.nsplit[0], a.nsplit[1]), max(a.nsplit[2], a.nsplit[3]));
+  }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 e1[NF], e2[MODE == GDN_IGDN_BWD ? NF : 1];
+  // groups of 4 pieces: bounded by the 256-VGPR budget (the whole tile in flight at once spills and
+  // measured no faster: 129 vs 125 us for igdn2.fwd at the bench shape)
+  constexpr int G = NF < 4 ? NF : 4;
+  static_assert(NF % G == 0, "piece groups");
+#pragma unroll
+  for (int k0 = 0; k0 < NF; k0 += G) {
+    f32x4 t[G], uu[MODE == GDN_IGDN_BWD ? G : 1], ss[MODE == GDN_IGDN_BWD ? G : 1];
+    int fo[G], srow[G];
+    bool ok[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int f = (k0 + g) * NT + tid;
+      ok[g] = f < fvalid;
+      fo[g] = ok[g] ? f * 4 : 0;
+      srow[g] = a.nsplit[0];
+      if (a.s_out == 2) {                        // transposed conv: the split factor depends on the phase
+        const long long m = m0 + f / C4;
+        const int ox = (int)(m % a.wout), oy = (int)((m / a.wout) % a.hout);
+        const int ph = (oy & 1) * 2 + (ox & 1);
+        srow[g] = ph == 0 ? a.nsplit[0] : (ph == 1 ? a.nsplit[1] : (ph == 2 ? a.nsplit[2] : a.nsplit[3]));
+      }
+    }
+    if constexpr (PRO == GDN_PRO_CONV3) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int f = (k0 + g) * NT + tid;
+        const int row = f / C4, c4 = f - row * C4;
+        t[g] = *reinterpret_cast<const f32x4*>(&Tt[row * TP + c4 * 4]);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) t[g] = ld4(src0 + fo[g]);
+    }
+    if constexpr (MODE == GDN_IGDN_BWD) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        uu[g] = ld4(up + fo[g]);
+        ss[g] = ld4(sp + fo[g]);
+      }
+    }
+    if constexpr (PRO != GDN_PRO_CONV3) {
+#pragma unroll 4
+      for (int s = 1; s < smax; ++s) {           // fixed order (= splitk_reduce_kernel), uniform trip count
+        const float* __restrict__ ps = src0 + (size_t)s * a.slab;
+        f32x4 x[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) x[g] = ld4(ps + fo[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) t[g] = s < srow[g] ? t[g] + x[g] : t[g];
+      }
+      if (a.bias) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int f = (k0 + g) * NT + tid;
+          t[g] += ld4(a.bias + (f % C4) * 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int f = (k0 + g) * NT + tid;
+      const int row = f / C4, c4 = f - row * C4;
+      f32x4 av;
+      if constexpr (MODE == GDN_IGDN_BWD) {
+        av = t[g] * uu[g] / ss[g];               // operand of the contraction: g*u/s
+        e1[k0 + g] = t[g] * ss[g];               // g*s
+        e2[k0 + g] = uu[g];
+      } else {
+        av = t[g] * t[g];
+        e1[k0 + g] = t[g];
+      }
+      *reinterpret_cast<f32x4*>(&Tt[row * TP + c4 * 4]) = ok[g] ? av : zero4;
+    }
+    __builtin_amdgcn_sched_barrier(0);           // keep the next group's loads out of this group (VGPR budget)
+  }
+
+  // ---- C x C contraction with gamma, A resident in the tile ------------------------------------
+  zero_acc();
+#pragma unroll 1
+  for (int kc = 0; kc < NC; ++kc) {
+    store_b();
+    __syncthreads();                             // (kc = 0: also publishes the tile)
+    if (kc + 1 < NC) load_b(gw, C, (kc + 1) * 32);
+    mfma_step(Tt, TP, kc * 32);
+    __syncthreads();
+  }
+  acc_to_tile();
+  __syncthreads();
+
+  // ---- epilogue: row-major 16-byte pieces, operands from registers ----------------------------
+#pragma unroll
+  for (int k = 0; k < NF; ++k) {
+    const int f = k * NT + tid;
+    const int row = f / C4, c4 = f - row * C4;
+    if (f >= fvalid) continue;
+    const size_t e = (size_t)m0 * C + (size_t)f * 4;
+    const f32x4 n = *reinterpret_cast<const f32x4*>(&Tt[row * TP + c4 * 4]);
+    if constexpr (MODE == GDN_IGDN_BWD) {
+      *reinterpret_cast<f32x4*>(a.out + e) = e1[k] + e2[k] * n;
+    } else {
+      const f32x4 nb = n + ld4(a.beta + c4 * 4);
+      f32x4 sq, v;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) sq[x] = sqrtf(nb[x]);
+      if constexpr (MODE == GDN_IGDN_FWD) {
+        v = e1[k] * sq;
+        if (a.s_out_p) *reinterpret_cast<f32x4*>(a.s_out_p + e) = sq;
+      } else {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] = e1[k][x] / sq[x];
+      }
+      if (a.u_out) *reinterpret_cast<f32x4*>(a.u_out + e) = e1[k];
+      *reinterpret_cast<f32x4*>(a.out + e) = v;
+    }
+    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NC, int WM, int WN, int MODE, int PRO>
+int launch_inst(const GdnArgs& a, hipStream_t stream) {
+  constexpr int C = NC * 32, BM = WM * 32, NT = WM * WN * 64;
+  const size_t lds = (size_t)(BM * (C + 4) + C * LDK) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_tile_kernel<NC, WM, WN, MODE, PRO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const long long grid = (a.M + BM - 1) / BM;
+  if (grid <= 0 || grid > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((gdn_tile_kernel<NC, WM, WN, MODE, PRO>), dim3((unsigned)grid), dim3(NT), lds, stream, a);
+  return (int)hipGetLastError();
+}
+
+template <int NC, int WM, int WN>
+int launch_mode(const GdnArgs& a, hipStream_t s) {
+  if (a.pro == GDN_PRO_CONV3) {
+    if (a.mode != GDN_IGDN_BWD) return (int)hipErrorInvalidValue;
+    if constexpr (WM * 32 % (WM * WN * 8) == 0)
+      return launch_inst<NC, WM, WN, GDN_IGDN_BWD, GDN_PRO_CONV3>(a, s);
+    else
+      return (int)hipErrorInvalidValue;
+  }
+  switch (a.mode) {
+    case GDN_IGDN_FWD: return launch_inst<NC, WM, WN, GDN_IGDN_FWD, GDN_PRO_LOAD>(a, s);
+    case GDN_GDN_FWD: return launch_inst<NC, WM, WN, GDN_GDN_FWD, GDN_PRO_LOAD>(a, s);
+    case GDN_IGDN_BWD: return launch_inst<NC, WM, WN, GDN_IGDN_BWD, GDN_PRO_LOAD>(a, s);
+  }
+  return (int)hipErrorInvalidValue;
+}
+
+// tile shapes: "general" = 2 workgroups per CU of 4 waves; "small" = 32-row tiles with one 32x32
+// block per wave, for launches that would otherwise leave most of the 256 CUs idle
+void pick_shape(int C, long long M, bool conv3, int& wm, int& wn) {
+  const int nc = C / 32;
+  if (nc == 8) { wm = 1; wn = 4; } else { wm = 2; wn = 2; }
+  const long long tiles = (M + wm * 32 - 1) / (wm * 32);
+  static const int force = [] { const char* e = getenv("SGA_GDN_SHAPE"); return e ? atoi(e) : 0; }();   // experiments
+  if (((tiles < 256 && force != 2) || force == 1) && !conv3) { wm = 1; wn = nc; }
+}
+
+}  // namespace
+
+int gdn_tile_rows(int C, long long M, int pro) {
+  int wm, wn;
+  pick_shape(C, M, pro == GDN_PRO_CONV3, wm, wn);
+  return wm * 32;
+}
+
+void gdn_kernel_name(const GdnArgs& a, char* out, int len) {
+  int wm, wn;
+  pick_shape(a.C, a.M, a.pro == GDN_PRO_CONV3, wm, wn);
+  snprintf(out, len, "gdn_tile_kernel<%d,%d,%d,%d,%d>", a.C / 32, wm, wn, a.mode, a.pro);
+}
+
+int launch_gdn_tile(const GdnArgs& a, hipStream_t s) {
+  int wm, wn;
+  pick_shape(a.C, a.M, a.pro == GDN_PRO_CONV3, wm, wn);
+  switch (a.C / 32) {
+    case 2: return (wm == 1) ? launch_mode<2, 1, 2>(a, s) : launch_mode<2, 2, 2>(a, s);
+    case 4: return (wm == 1) ? launch_mode<4, 1, 4>(a, s) : launch_mode<4, 2, 2>(a, s);
+    case 6: return (wm == 1) ? launch_mode<6, 1, 6>(a, s) : launch_mode<6, 2, 2>(a, s);
+    case 8: return (wn == 8) ? launch_mode<8, 1, 8>(a, s) : launch_mode<8, 1, 4>(a, s);
+  }
+  return (int)hipErrorInvalidValue;
+}

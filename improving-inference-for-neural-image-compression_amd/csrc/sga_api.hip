@@ -100,6 +100,7 @@ struct sga_handle {
   int run_B = 0, run_H = 0, run_W = 0, run_its = -1, run_it = 0;   // sga_run_begin/steps state
   float run_lambda = 0.f, run_loss_scale = 1.f; uint64_t run_seed = 0;
   bool split256 = true;            // split-K also for a single-phase launch of exactly 256 tiles (SGA_SPLIT256=0: off)
+  bool fused_gdn = true;           // gdn_fused.hip instead of the stand-alone GDN launches (SGA_FUSED_GDN=0: off)
   bool bm256 = true;               // 256-row 8-wave tile for big unsplit f32 launches (SGA_BM256=0: off)
   bool first_after_fork = false;   // set at the fork, consumed by the next main-stream conv_launch
   int x3_mask = 3;                 // SGA_X3_MASK
@@ -187,8 +188,17 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   return smax;
 }
 
+// A convolution whose split-K partial slabs are left un-reduced for the kernel that consumes its
+// output (gdn_tile_kernel sums them in its prologue): what that kernel needs to know.
+struct Deferred {
+  bool active = false;       // false: the convolution wrote its complete output (bias included)
+  const float* part = nullptr; long long slab = 0; int nsplit[4] = {1, 1, 1, 1};
+  int s_out = 1, hout = 0, wout = 0;
+  const float* bias = nullptr;
+};
+
 // every MFMA convolution goes through here (so it can be timed)
-int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st) {
+int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nullptr) {
   // 256-row tile (8 waves): each weight byte feeds twice the MFMAs; only for big unsplit f32 launches
   a.bm = 128;
   if (h->bm256 && !h->x3 && !a.smallc && a.pro == PRO_NONE && a.Npad / a.ntiles_n == 192 &&
@@ -198,6 +208,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st) {
     a.tiles_per_phase = (a.tiles_per_phase + 1) / 2;
   }
   a.ksplit = pick_ksplit(h, a);
+  if (defer && a.epi != EPI_BIAS) return SGA_ERR_BAD_ARG;   // the consumer applies "+ bias" only
   // bf16x3 where it is faster: the IGDN-backward prologue (3 prefetched operands) and the 2-wave
   // BN=96 tile spill to scratch in that mode and measured slower than their f32 instances (193 vs
   // 177 us, 96 vs 88 us), so those launches stay on the f32 MFMA kernel (2.21 -> 2.30 img/s).
@@ -234,7 +245,16 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st) {
     HIPCHK(h, hipEventRecord(r.b, st));
     h->prof.push_back(r);
   }
-  if (a.ksplit > 1) HIPCHK(h, launch_splitk_reduce(a, n_out, st));
+  if (defer) {
+    defer->active = a.ksplit > 1;
+    if (defer->active) {
+      defer->part = a.part; defer->slab = a.slab; defer->bias = a.bias;
+      defer->s_out = a.s_out; defer->hout = a.Hout; defer->wout = a.Wout;
+      for (int p = 0; p < 4; ++p) defer->nsplit[p] = a.nsplit[p] > 0 ? a.nsplit[p] : 1;
+      if (a.s_out != 2) for (int p = 1; p < 4; ++p) defer->nsplit[p] = defer->nsplit[0];
+    }
+  }
+  if (a.ksplit > 1 && !defer) HIPCHK(h, launch_splitk_reduce(a, n_out, st));
   if (h->profiling && h->profile_by_layer) {    // layer-level stats: conv + its reduce
     HIPCHK(h, hipEventRecord(r.b, st));
     h->prof.push_back(r);
@@ -472,27 +492,28 @@ ConvArgs base_args(const PackedConv& pc, int B, int Hg, int Wg) {
 // ---- layer launchers (all: in/out NHWC device) ---------------------------------------------
 // transposed 5x5/2: [B,Hi,Wi,Cin] -> [B,2Hi,2Wi,Cout]
 int deconv_fwd(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int B,
-               int Hi, int Wi, float* out, int epi, hipStream_t st) {
+               int Hi, int Wi, float* out, int epi, hipStream_t st, Deferred* defer = nullptr) {
   ConvArgs a = base_args(pc, B, Hi, Wi);
   a.in = in; a.out = out; a.bias = bias;
   a.Hin = Hi; a.Win = Wi; a.Hout = 2 * Hi; a.Wout = 2 * Wi;
   a.s_in = 1; a.s_out = 2; a.epi = epi;
   taps_deconv5_s2(a);
   a.flops = 2.0 * B * Hi * Wi * 25.0 * pc.Kc * pc.N;
-  return conv_launch(h, a, st);
+  return conv_launch(h, a, st, defer);
 }
 
 // stride-2 5x5 conv over `in` [B,Hi,Wi,K] -> [B,Ho,Wo,N]; used for analysis forward and for the
 // data-gradient of deconv_fwd (then in = g_out, Ho = Hi/2).  aux0: ReLU-mask activation (or null)
 int conv5s2(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int B, int Hi,
-            int Wi, int Ho, int Wo, float* out, int epi, const float* aux0, hipStream_t st) {
+            int Wi, int Ho, int Wo, float* out, int epi, const float* aux0, hipStream_t st,
+            Deferred* defer = nullptr) {
   ConvArgs a = base_args(pc, B, Ho, Wo);
   a.in = in; a.out = out; a.bias = bias; a.aux0 = aux0;
   a.Hin = Hi; a.Win = Wi; a.Hout = Ho; a.Wout = Wo;
   a.s_in = 2; a.s_out = 1; a.epi = epi;
   taps_conv5_s2(a);
   a.flops = 2.0 * B * Ho * Wo * 25.0 * pc.Kc * pc.N;
-  return conv_launch(h, a, st);
+  return conv_launch(h, a, st, defer);
 }
 
 int conv3(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int in_cs, int B,
@@ -506,9 +527,54 @@ int conv3(sga_handle* h, const PackedConv& pc, const float* bias, const float* i
   return conv_launch(h, a, st);
 }
 
-// GDN / IGDN forward on u [B,Hh,Ww,C]: out = u * sqrt(n) (inverse) or u / sqrt(n); s_out = sqrt(n)
-int gdn_fwd(sga_handle* h, const PackedConv& pc, const float* beta, const float* u, int B, int Hh,
-            int Ww, float* s_out, float* out, bool inverse, hipStream_t st) {
+// one launch of the fused GDN tile kernel (gdn_fused.hip), timed like the convolutions
+int gdn_launch(sga_handle* h, GdnArgs& g, hipStream_t st) {
+  sga_handle::ProfRec r;
+  if (h->profiling) {
+    r.flops = g.flops;
+    char kn[64];
+    gdn_kernel_name(g, kn, sizeof(kn));
+    if (h->profile_by_layer) snprintf(r.name, sizeof(r.name), "%s %s", h->cur_tag, kn);
+    else snprintf(r.name, sizeof(r.name), "%s", kn);
+    HIPCHK(h, hipEventCreate(&r.a));
+    HIPCHK(h, hipEventCreate(&r.b));
+    HIPCHK(h, hipEventRecord(r.a, st));
+  }
+  HIPCHK(h, launch_gdn_tile(g, st));
+  if (h->profiling) {
+    HIPCHK(h, hipEventRecord(r.b, st));
+    h->prof.push_back(r);
+  }
+  return SGA_OK;
+}
+
+void gdn_source(GdnArgs& g, const float* tensor, const Deferred* d) {
+  for (int p = 0; p < 4; ++p) g.nsplit[p] = 1;
+  g.s_out = 1; g.src = tensor; g.slab = 0; g.bias = nullptr;
+  if (d && d->active) {
+    g.src = d->part; g.slab = d->slab; g.bias = d->bias;
+    g.s_out = d->s_out; g.hout = d->hout; g.wout = d->wout;
+    for (int p = 0; p < 4; ++p) g.nsplit[p] = d->nsplit[p];
+  }
+}
+
+// GDN / IGDN forward on u [B,Hh,Ww,C]: out = u * sqrt(n) (inverse) or u / sqrt(n); s_out = sqrt(n).
+// d (optional): u has not been assembled yet -- it is the sum of the producing convolution's split-K
+// slabs + bias; the kernel assembles it in its prologue and writes it to `u` as well.
+int gdn_fwd(sga_handle* h, const PackedConv& pc, const float* beta, float* u, int B, int Hh,
+            int Ww, float* s_out, float* out, bool inverse, hipStream_t st, const Deferred* d = nullptr) {
+  if (h->fused_gdn) {
+    GdnArgs g;
+    memset(&g, 0, sizeof(g));
+    g.C = pc.N; g.mode = inverse ? GDN_IGDN_FWD : GDN_GDN_FWD; g.pro = GDN_PRO_LOAD;
+    g.M = (long long)B * Hh * Ww;
+    gdn_source(g, u, d);
+    g.w = pc.w; g.beta = beta; g.out = out; g.s_out_p = s_out;
+    g.u_out = (d && d->active) ? u : nullptr;
+    g.flops = 2.0 * B * Hh * Ww * (double)pc.Kc * pc.N;
+    return gdn_launch(h, g, st);
+  }
+  if (d && d->active) return SGA_ERR_BAD_ARG;
   ConvArgs a = base_args(pc, B, Hh, Ww);
   a.in = u; a.out = out; a.bias = beta; a.aux0 = u; a.aux_out = s_out;
   a.Hin = Hh; a.Win = Ww; a.Hout = Hh; a.Wout = Ww;
@@ -518,9 +584,24 @@ int gdn_fwd(sga_handle* h, const PackedConv& pc, const float* beta, const float*
   return conv_launch(h, a, st);
 }
 
-// IGDN backward: g_u = g_v * s + u * (gamma . (g_v * u / s))
+// IGDN backward: g_u = g_v * s + u * (gamma . (g_v * u / s)).  g_v is a tensor, or (d) the un-reduced
+// split-K slabs of the convolution that produces it, or (gpad != null) the 5x5/2 convolution of the
+// zero-bordered 3-channel gradient image with the C->3 layer's kernel, computed in the same launch.
 int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float* u, const float* s,
-             int B, int Hh, int Ww, float* g_u, hipStream_t st) {
+             int B, int Hh, int Ww, float* g_u, hipStream_t st, const Deferred* d = nullptr,
+             const float* gpad = nullptr, const PackedConv* pc3 = nullptr, int Hp = 0, int Wp = 0) {
+  if (h->fused_gdn) {
+    GdnArgs g;
+    memset(&g, 0, sizeof(g));
+    g.C = pc.N; g.mode = GDN_IGDN_BWD; g.pro = gpad ? GDN_PRO_CONV3 : GDN_PRO_LOAD;
+    g.M = (long long)B * Hh * Ww;
+    gdn_source(g, g_v, d);
+    if (gpad) { g.pad = gpad; g.wc = pc3->w; g.Hg = Hh; g.Wg = Ww; g.Hp = Hp; g.Wp = Wp; }
+    g.w = pc.w; g.u = u; g.s = s; g.out = g_u;
+    g.flops = 2.0 * B * Hh * Ww * (double)pc.Kc * pc.N + (gpad ? 2.0 * B * Hh * Ww * 75.0 * pc.N : 0.0);
+    return gdn_launch(h, g, st);
+  }
+  if ((d && d->active) || gpad) return SGA_ERR_BAD_ARG;
   ConvArgs a = base_args(pc, B, Hh, Ww);
   a.in = g_v; a.aux1 = s; a.aux2 = u; a.out = g_u;
   a.Hin = Hh; a.Win = Ww; a.Hout = Hh; a.Wout = Ww;
@@ -655,12 +736,16 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   static const char* kIgdn[3] = {"igdn0.fwd", "igdn1.fwd", "igdn2.fwd"};
   static const char* kIgdnB[3] = {"igdn0.bwd", "igdn1.bwd", "igdn2.bwd"};
   static const char* kBwd[3] = {"gs0.bwd", "gs1.bwd", "gs2.bwd"};
+  // Layers whose tile grid under-fills the chip run split-K; their partial slabs are summed (+ bias)
+  // by the IGDN kernel that follows instead of by a reduce launch (fused_gdn).
+  const bool fz = h->fused_gdn;
   for (int L = 0; L < 3; ++L) {
+    Deferred d;
     h->cur_tag = kFwd[L];
-    SGACHK(deconv_fwd(h, h->gs_f[L], h->gs_bias[L], cur, B, hh, ww, h->u[L].p, EPI_BIAS, st));
+    SGACHK(deconv_fwd(h, h->gs_f[L], h->gs_bias[L], cur, B, hh, ww, h->u[L].p, EPI_BIAS, st, fz ? &d : nullptr));
     hh *= 2; ww *= 2;
     h->cur_tag = kIgdn[L];
-    SGACHK(gdn_fwd(h, h->gs_gdn_f[L], h->gs_beta[L], h->u[L].p, B, hh, ww, h->s[L].p, h->v[L].p, true, st));
+    SGACHK(gdn_fwd(h, h->gs_gdn_f[L], h->gs_beta[L], h->u[L].p, B, hh, ww, h->s[L].p, h->v[L].p, true, st, &d));
     cur = h->v[L].p;
   }
   h->cur_tag = "gs3.fwd";
@@ -669,14 +754,25 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
                        with_grad ? h->gpad.p : nullptr, with_grad ? nullptr : h->xq.p, st));
   if (!with_grad) return SGA_OK;
   // hh,ww = 8yh,8yw: gradient w.r.t. v[2] from the bordered gradient image
-  h->cur_tag = "gs3.bwd";
-  SGACHK(conv_smallc(h, h->gs_b[3], nullptr, h->gpad.p, B, g.Hp, g.Wp, hh, ww, h->gA.p, st));
+  // gs3.bwd (the 5x5/2 conv of the 3-channel gradient image) is the prologue of igdn2.bwd when fused
+  const bool conv3_fused = fz;
+  if (!conv3_fused) {
+    h->cur_tag = "gs3.bwd";
+    SGACHK(conv_smallc(h, h->gs_b[3], nullptr, h->gpad.p, B, g.Hp, g.Wp, hh, ww, h->gA.p, st));
+  }
+  Deferred d;
   for (int L = 2; L >= 0; --L) {
     h->cur_tag = kIgdnB[L];
-    SGACHK(igdn_bwd(h, h->gs_gdn_b[L], h->gA.p, h->u[L].p, h->s[L].p, B, hh, ww, h->gB.p, st));
+    if (L == 2 && conv3_fused)
+      SGACHK(igdn_bwd(h, h->gs_gdn_b[L], nullptr, h->u[L].p, h->s[L].p, B, hh, ww, h->gB.p, st, nullptr,
+                      h->gpad.p, &h->gs_b[3], g.Hp, g.Wp));
+    else
+      SGACHK(igdn_bwd(h, h->gs_gdn_b[L], h->gA.p, h->u[L].p, h->s[L].p, B, hh, ww, h->gB.p, st, &d));
     float* dst = (L == 0) ? h->g_yt_dist.p : h->gA.p;
     h->cur_tag = kBwd[L];
-    SGACHK(conv5s2(h, h->gs_b[L], nullptr, h->gB.p, B, hh, ww, hh / 2, ww / 2, dst, EPI_BIAS, nullptr, st));
+    d = Deferred();
+    SGACHK(conv5s2(h, h->gs_b[L], nullptr, h->gB.p, B, hh, ww, hh / 2, ww / 2, dst, EPI_BIAS, nullptr, st,
+                   (fz && L > 0) ? &d : nullptr));
     hh /= 2; ww /= 2;
   }
   h->cur_tag = "";
@@ -1000,6 +1096,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->split256 = !(env && env[0] == '0');
   env = getenv("SGA_BM256");
   h->bm256 = !(env && env[0] == '0');
+  env = getenv("SGA_FUSED_GDN");
+  h->fused_gdn = !(env && env[0] == '0');
   env = getenv("SGA_X3_SKIP");
   if (env) strncpy(h->x3_skip, env, sizeof(h->x3_skip) - 1);
   env = getenv("SGA_X3_MASK");

@@ -101,6 +101,34 @@ int conv_pick_bn(int cout, int epi);
 // kernel symbol (as rocprofv3 prints it) that launch_conv will use for these args
 void conv_kernel_name(const ConvArgs& a, char* out, int len);
 
+// ---------------------------------------------------------------------------------------
+// GDN / IGDN tile kernel (gdn_fused.hip): prologue (slab sum | 3-channel conv) + resident-operand
+// C x C contraction + epilogue in one launch
+// ---------------------------------------------------------------------------------------
+enum GdnMode { GDN_IGDN_FWD = 0, GDN_GDN_FWD = 1, GDN_IGDN_BWD = 2 };
+enum GdnPrologue { GDN_PRO_LOAD = 0, GDN_PRO_CONV3 = 1 };
+struct GdnArgs {
+  int C, mode, pro;
+  long long M;             // pixels (rows); row m is the contiguous block [m*C, (m+1)*C) of every tensor
+  // GDN_PRO_LOAD: T = sum_{s < S} src[s*slab + .] (+ bias);  S = nsplit[0], or per sub-pixel phase of a
+  // stride-2 transposed conv (s_out == 2): nsplit[(oy&1)*2 + (ox&1)] with (oy, ox) from (hout, wout)
+  const float* src; long long slab; int nsplit[4]; int s_out, hout, wout;
+  const float* bias;
+  // GDN_PRO_CONV3: T = 5x5/2 conv of the zero-bordered image pad [B,Hp,Wp,3] over the Hg x Wg grid,
+  // weights wc [3][C][32] (pack_smallc)
+  const float* pad; const float* wc; int Hg, Wg, Hp, Wp;
+  const float* w;          // gamma, [C][C]: row = output channel, K contiguous (pack_gdn)
+  const float* beta;       // forward
+  const float* u; const float* s;     // backward: pre-IGDN activation and sqrt(n) of the forward pass
+  float* out;              // forward: v;  backward: g_u
+  float* s_out_p;          // forward IGDN: sqrt(n) (or null)
+  float* u_out;            // forward: T written back (needed when T was assembled here), or null
+  double flops;            // algorithmic flops (profiling only)
+};
+int launch_gdn_tile(const GdnArgs& a, hipStream_t stream);
+int gdn_tile_rows(int C, long long M, int pro);
+void gdn_kernel_name(const GdnArgs& a, char* out, int len);
+
 // C -> 3 transposed 5x5/2 conv, halo-tiled (deconv3.hip); w packed [C/32][9 taps][16][32]
 int launch_deconv3_halo(const float* in, const float* w, const float* bias, float* out, int B,
                         int Hi, int Wi, int C, int Ho, int Wo, hipStream_t stream);

@@ -1,0 +1,58 @@
+"""The fused GDN tile kernel (csrc/gdn_fused.hip: split-K slab sum or 3-channel conv prologue +
+resident-operand C x C contraction + epilogue, one launch) against the launches it replaces
+(conv -> splitk_reduce -> stand-alone GDN kernel; SGA_FUSED_GDN=0): the same f32 fmaf chains in the
+same order, so the two paths must agree BIT FOR BIT -- in the encoder (GDN forward,
+nn_models.py:17-25), in one SGA step (IGDN forward / backward, nn_models.py:51-59) and over a short
+run.  Parity of either path with the oracle is covered by the other GPU test files."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import sga_amd  # noqa: E402
+
+
+def _pair(C, B, H, W):
+    from sga_amd.codec import SGACodec
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    old = os.environ.get("SGA_FUSED_GDN")
+    try:
+        os.environ["SGA_FUSED_GDN"] = "1"
+        fused = SGACodec(w, C, B, H, W)
+        os.environ["SGA_FUSED_GDN"] = "0"
+        legacy = SGACodec(w, C, B, H, W)
+    finally:
+        if old is None:
+            os.environ.pop("SGA_FUSED_GDN", None)
+        else:
+            os.environ["SGA_FUSED_GDN"] = old
+    return fused, legacy
+
+
+# shapes: every tile shape of gdn_fused.hip (general / 32-row "small", C = 64..256), ragged sizes,
+# split and unsplit producers
+SHAPES = [(64, 2, 64, 64), (64, 1, 50, 70), (128, 1, 37, 41), (192, 2, 64, 48), (192, 1, 256, 256),
+          (256, 1, 96, 80), (192, 3, 128, 192), (256, 1, 200, 264)]
+
+
+@pytest.mark.parametrize("C,B,H,W", SHAPES)
+def test_fused_equals_unfused_bitwise(C, B, H, W):
+    fused, legacy = _pair(C, B, H, W)
+    x = np.random.RandomState(C + H).rand(B, H, W, 3).astype(np.float32)
+    ya, za = fused.encode(x)
+    yb, zb = legacy.encode(x)
+    assert torch.equal(ya, yb) and torch.equal(za, zb)            # GDN forward (analysis)
+    ra = fused.step_grads(x, ya, za, 0.4, 0.01, seed=3, it=5)
+    rb = legacy.step_grads(x, ya, za, 0.4, 0.01, seed=3, it=5)
+    assert torch.equal(ra["gy"], rb["gy"]) and torch.equal(ra["gz"], rb["gz"])
+    assert ra["rd_loss"] == rb["rd_loss"] and ra["train_mse"] == rb["train_mse"]
+    assert float(ra["gy"].abs().max()) > 0
+    its = 12 if H * W > 40000 else 30
+    a = fused.run(x, 0.01, its=its, seed=1)
+    b = legacy.run(x, 0.01, its=its, seed=1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[2][:, [0, 1, 4, 5, 6]], b[2][:, [0, 1, 4, 5, 6]])
+    fused.close(); legacy.close()
