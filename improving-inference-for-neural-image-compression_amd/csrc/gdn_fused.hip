@@ -41,6 +41,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
   constexpr int TP = C + 4;                      // tile pitch (floats)
   constexpr int C4 = C / 4;                      // float4 per tile row
   constexpr int NF = BM * C4 / NT;               // float4 pieces owned by a thread
+  // piece (kr, kc) of thread (pr, pc): tile row pr + R*kr, float4 column pc + CW*kc.  Every address is
+  // then one per-thread base + a compile-time offset (no per-piece address registers)
+  constexpr int CW = (WN == NC) ? C4 : 16, R = NT / CW, KR = BM / R, KC = C4 / CW;
+  static_assert(NT % CW == 0 && BM % R == 0 && C4 % CW == 0 && KR * KC == NF, "piece mapping");
   constexpr int RPP = NT / 8;                    // rows covered by one pass of the K-step loaders
   constexpr int PB = C / RPP;
   static_assert(NC % WN == 0 && (BM * C4) % NT == 0 && C % RPP == 0, "tile/loader mismatch");
@@ -77,6 +81,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
     const int arow = wm * 32 + col;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      // backward keeps 96 epilogue registers alive through this loop: stop the scheduler from hoisting
+      // all four q's fragment reads (64 VGPRs) above the MFMAs, which would spill
+      if (MODE == GDN_IGDN_BWD && TN >= 3 && (q & 1) == 0 && q) __builtin_amdgcn_sched_barrier(0);
       const f32x4 af = *reinterpret_cast<const f32x4*>(&A[arow * ap + k0 + q * 8 + koff]);
       f32x4 bf[TN];
 #pragma unroll
@@ -149,100 +156,86 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
     __syncthreads();
   }
 
-  load_b(gw, C, 0);                              // first K-step of gamma: in flight during the fill
+  // first K-step of gamma: in flight during the fill (backward: after it -- its three input streams
+  // leave no registers for it)
+  if constexpr (MODE != GDN_IGDN_BWD) load_b(gw, C, 0);
 
   // ---- fill: one coalesced pass over the tile's inputs ----------------------------------------
-  // The tile is the contiguous block [m0*C, (m0+BM)*C): piece f of it sits at float offset 4f.  All
-  // loads are unconditional (pieces past M re-read piece 0 and are discarded by a select) and issued
-  // in groups of G pieces so that a group's loads are in flight together.
+  // All loads are unconditional (rows past M re-read row m0 and are discarded by a select) and issued
+  // one tile-row group (KC pieces per stream) at a time.
+  const int pr = tid / CW, pc = tid - pr * CW;
   const long long rows_left = a.M - m0;
-  const int fvalid = rows_left >= BM ? BM * C4 : (int)rows_left * C4;      // pieces f < fvalid are real
-  const float* __restrict__ src0 = a.src ? a.src + (size_t)m0 * C : nullptr;
-  const float* __restrict__ up = (MODE == GDN_IGDN_BWD) ? a.u + (size_t)m0 * C : nullptr;
-  const float* __restrict__ sp = (MODE == GDN_IGDN_BWD) ? a.s + (size_t)m0 * C : nullptr;
+  const int rvalid = rows_left >= BM ? BM : (int)rows_left;                // rows r < rvalid are real
+  const size_t tbase = (size_t)m0 * C + (size_t)pc * 4;                    // + row * C + kc * CW * 4
+  float* const tp = Tt + pr * TP + pc * 4;                                 // + kr * R * TP + kc * CW * 4
   int smax = a.nsplit[0];
-  if (a.s_out == 2) {
-    smax = max(max(a.nsplit[0], a.nsplit[1]), max(a.nsplit[2], a.nsplit[3]));
-  }
+  if (a.s_out == 2) smax = max(max(a.nsplit[0], a.nsplit[1]), max(a.nsplit[2], a.nsplit[3]));
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 e1[NF], e2[MODE == GDN_IGDN_BWD ? NF : 1];
-  // groups of 4 pieces: bounded by the 256-VGPR budget (the whole tile in flight at once spills and
-  // measured no faster: 129 vs 125 us for igdn2.fwd at the bench shape)
-  constexpr int G = NF < 4 ? NF : 4;
-  static_assert(NF % G == 0, "piece groups");
 #pragma unroll
-  for (int k0 = 0; k0 < NF; k0 += G) {
-    f32x4 t[G], uu[MODE == GDN_IGDN_BWD ? G : 1], ss[MODE == GDN_IGDN_BWD ? G : 1];
-    int fo[G], srow[G];
-    bool ok[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const int f = (k0 + g) * NT + tid;
-      ok[g] = f < fvalid;
-      fo[g] = ok[g] ? f * 4 : 0;
-      srow[g] = a.nsplit[0];
-      if (a.s_out == 2) {                        // transposed conv: the split factor depends on the phase
-        const long long m = m0 + f / C4;
-        const int ox = (int)(m % a.wout), oy = (int)((m / a.wout) % a.hout);
-        const int ph = (oy & 1) * 2 + (ox & 1);
-        srow[g] = ph == 0 ? a.nsplit[0] : (ph == 1 ? a.nsplit[1] : (ph == 2 ? a.nsplit[2] : a.nsplit[3]));
-      }
-    }
+  for (int kr = 0; kr < KR; ++kr) {
+    const int row = pr + R * kr;
+    const bool ok = row < rvalid;
+    const size_t ro = tbase + (size_t)(ok ? row : 0) * C;
+    f32x4 t[KC], uu[MODE == GDN_IGDN_BWD ? KC : 1], ss[MODE == GDN_IGDN_BWD ? KC : 1];
     if constexpr (PRO == GDN_PRO_CONV3) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const int f = (k0 + g) * NT + tid;
-        const int row = f / C4, c4 = f - row * C4;
-        t[g] = *reinterpret_cast<const f32x4*>(&Tt[row * TP + c4 * 4]);
-      }
+      for (int kc = 0; kc < KC; ++kc) t[kc] = *reinterpret_cast<const f32x4*>(tp + kr * R * TP + kc * CW * 4);
     } else {
 #pragma unroll
-      for (int g = 0; g < G; ++g) t[g] = ld4(src0 + fo[g]);
+      for (int kc = 0; kc < KC; ++kc) t[kc] = ld4(a.src + ro + kc * CW * 4);
     }
     if constexpr (MODE == GDN_IGDN_BWD) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        uu[g] = ld4(up + fo[g]);
-        ss[g] = ld4(sp + fo[g]);
+      for (int kc = 0; kc < KC; ++kc) {
+        uu[kc] = ld4(a.u + ro + kc * CW * 4);
+        ss[kc] = ld4(a.s + ro + kc * CW * 4);
       }
     }
     if constexpr (PRO != GDN_PRO_CONV3) {
+      if (smax > 1) {
+        int srow = a.nsplit[0];
+        if (a.s_out == 2) {                      // transposed conv: the split factor depends on the phase
+          const long long m = m0 + row;
+          const int ox = (int)(m % a.wout), oy = (int)((m / a.wout) % a.hout);
+          const int ph = (oy & 1) * 2 + (ox & 1);
+          srow = ph == 0 ? a.nsplit[0] : (ph == 1 ? a.nsplit[1] : (ph == 2 ? a.nsplit[2] : a.nsplit[3]));
+        }
 #pragma unroll 4
-      for (int s = 1; s < smax; ++s) {           // fixed order (= splitk_reduce_kernel), uniform trip count
-        const float* __restrict__ ps = src0 + (size_t)s * a.slab;
-        f32x4 x[G];
+        for (int s = 1; s < smax; ++s) {         // fixed order (= splitk_reduce_kernel), uniform trip count
+          const float* __restrict__ ps = a.src + (size_t)s * a.slab + ro;
+          f32x4 x[KC];
 #pragma unroll
-        for (int g = 0; g < G; ++g) x[g] = ld4(ps + fo[g]);
+          for (int kc = 0; kc < KC; ++kc) x[kc] = ld4(ps + kc * CW * 4);
 #pragma unroll
-        for (int g = 0; g < G; ++g) t[g] = s < srow[g] ? t[g] + x[g] : t[g];
+          for (int kc = 0; kc < KC; ++kc) t[kc] = s < srow ? t[kc] + x[kc] : t[kc];
+        }
       }
       if (a.bias) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const int f = (k0 + g) * NT + tid;
-          t[g] += ld4(a.bias + (f % C4) * 4);
-        }
+        for (int kc = 0; kc < KC; ++kc) t[kc] += ld4(a.bias + pc * 4 + kc * CW * 4);
       }
     }
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const int f = (k0 + g) * NT + tid;
-      const int row = f / C4, c4 = f - row * C4;
+    for (int kc = 0; kc < KC; ++kc) {
       f32x4 av;
       if constexpr (MODE == GDN_IGDN_BWD) {
-        av = t[g] * uu[g] / ss[g];               // operand of the contraction: g*u/s
-        e1[k0 + g] = t[g] * ss[g];               // g*s
-        e2[k0 + g] = uu[g];
+        av = t[kc] * uu[kc] / ss[kc];            // operand of the contraction: g*u/s
+        e1[kr * KC + kc] = t[kc] * ss[kc];       // g*s
+        e2[kr * KC + kc] = uu[kc];
       } else {
-        av = t[g] * t[g];
-        e1[k0 + g] = t[g];
+        av = t[kc] * t[kc];
+        e1[kr * KC + kc] = t[kc];
       }
-      *reinterpret_cast<f32x4*>(&Tt[row * TP + c4 * 4]) = ok[g] ? av : zero4;
+      *reinterpret_cast<f32x4*>(tp + kr * R * TP + kc * CW * 4) = ok ? av : zero4;
     }
-    __builtin_amdgcn_sched_barrier(0);           // keep the next group's loads out of this group (VGPR budget)
+    // keep the next row group's loads out of this one (VGPR budget of the backward instances)
+    if constexpr (MODE == GDN_IGDN_BWD) asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- C x C contraction with gamma, A resident in the tile ------------------------------------
+  if constexpr (MODE == GDN_IGDN_BWD) load_b(gw, C, 0);
   zero_acc();
 #pragma unroll 1
   for (int kc = 0; kc < NC; ++kc) {
@@ -257,30 +250,35 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
 
   // ---- epilogue: row-major 16-byte pieces, operands from registers ----------------------------
 #pragma unroll
-  for (int k = 0; k < NF; ++k) {
-    const int f = k * NT + tid;
-    const int row = f / C4, c4 = f - row * C4;
-    if (f >= fvalid) continue;
-    const size_t e = (size_t)m0 * C + (size_t)f * 4;
-    const f32x4 n = *reinterpret_cast<const f32x4*>(&Tt[row * TP + c4 * 4]);
-    if constexpr (MODE == GDN_IGDN_BWD) {
-      *reinterpret_cast<f32x4*>(a.out + e) = e1[k] + e2[k] * n;
-    } else {
-      const f32x4 nb = n + ld4(a.beta + c4 * 4);
-      f32x4 sq, v;
+  for (int kr = 0; kr < KR; ++kr) {
+    const int row = pr + R * kr;
+    if (row < rvalid) {
+      const size_t ro = tbase + (size_t)row * C;
 #pragma unroll
-      for (int x = 0; x < 4; ++x) sq[x] = sqrtf(nb[x]);
-      if constexpr (MODE == GDN_IGDN_FWD) {
-        v = e1[k] * sq;
-        if (a.s_out_p) *reinterpret_cast<f32x4*>(a.s_out_p + e) = sq;
-      } else {
+      for (int kc = 0; kc < KC; ++kc) {
+        const int k = kr * KC + kc;
+        const size_t e = ro + kc * CW * 4;
+        const f32x4 n = *reinterpret_cast<const f32x4*>(tp + kr * R * TP + kc * CW * 4);
+        if constexpr (MODE == GDN_IGDN_BWD) {
+          *reinterpret_cast<f32x4*>(a.out + e) = e1[k] + e2[k] * n;
+        } else {
+          const f32x4 nb = n + ld4(a.beta + pc * 4 + kc * CW * 4);
+          f32x4 sq, v;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) v[x] = e1[k][x] / sq[x];
+          for (int x = 0; x < 4; ++x) sq[x] = sqrtf(nb[x]);
+          if constexpr (MODE == GDN_IGDN_FWD) {
+            v = e1[k] * sq;
+            if (a.s_out_p) *reinterpret_cast<f32x4*>(a.s_out_p + e) = sq;
+          } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) v[x] = e1[k][x] / sq[x];
+          }
+          if (a.u_out) *reinterpret_cast<f32x4*>(a.u_out + e) = e1[k];
+          *reinterpret_cast<f32x4*>(a.out + e) = v;
+        }
       }
-      if (a.u_out) *reinterpret_cast<f32x4*>(a.u_out + e) = e1[k];
-      *reinterpret_cast<f32x4*>(a.out + e) = v;
     }
-    if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

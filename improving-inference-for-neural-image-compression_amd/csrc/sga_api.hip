@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <vector>
 
@@ -96,17 +97,13 @@ struct sga_handle {
   hipStream_t sB = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;           // eager launches
   const char* dump_path = nullptr; unsigned long long* dump = nullptr; int dump_run = 0;   // SGA_DEBUG_DUMP
-  char x3_skip[128] = {0};         // SGA_X3_SKIP="gs0.fwd,gs1.bwd" (experiments)
   int run_B = 0, run_H = 0, run_W = 0, run_its = -1, run_it = 0;   // sga_run_begin/steps state
   float run_lambda = 0.f, run_loss_scale = 1.f; uint64_t run_seed = 0;
   bool split256 = true;            // split-K also for a single-phase launch of exactly 256 tiles (SGA_SPLIT256=0: off)
   bool fused_gdn = true;           // gdn_fused.hip instead of the stand-alone GDN launches (SGA_FUSED_GDN=0: off)
   bool bm256 = true;               // 256-row 8-wave tile for big unsplit f32 launches (SGA_BM256=0: off)
-  bool first_after_fork = false;   // set at the fork, consumed by the next main-stream conv_launch
-  int x3_mask = 3;                 // SGA_X3_MASK
-  int dbg_delay_us = 0;            // SGA_DEBUG_DELAY_US: stall the side branch (experiments)
-  bool fences = true;              // SGA_NO_FENCES=1 removes the one-wave kernels around fork/join
-  int dbg_fork = 0, dbg_it = -1; int* dbg_bad = nullptr;     // SGA_DEBUG_FORK=1
+  int fork_at = 0;                 // main-chain launch index at which the hyper branch is forked (SGA_FORK_AT)
+  int dbg_it = -1;                 // iteration being enqueued (SGA_DEBUG_DUMP)
   hipEvent_t ev_fork_cap = nullptr, ev_join_cap = nullptr;   // while `st` is being captured
   bool overlap = true;             // SGA_NO_OVERLAP=1 disables
   ImgSums* sums = nullptr;
@@ -214,16 +211,6 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   // 177 us, 96 vs 88 us), so those launches stay on the f32 MFMA kernel (2.21 -> 2.30 img/s).
   a.x3 = (h->x3 && a.w3 && !a.smallc && a.epi != EPI_SHUFFLE3 && a.pro != PRO_IGDN_BWD &&
           a.Npad / a.ntiles_n != 96) ? 1 : 0;
-  if (a.x3 && !(h->x3_mask & (st == h->sB ? 2 : 1))) a.x3 = 0;   // SGA_X3_MASK (experiments)
-  // bf16x3 with two streams: the main-stream convolution that starts together with the side branch
-  // stays on the f32 kernel.  With it in bf16x3, identical 2000-iteration runs ended in different
-  // latents in 7 of 25 cases (the first side-stream kernel read stale inputs); with this rule 25
-  // of 25 graph-replay and 17 of 17 eager runs are bit-identical.
-  if (a.x3 && h->first_after_fork && st != h->sB) a.x3 = 0;
-  if (st != h->sB) h->first_after_fork = false;
-  if (a.x3 && h->x3_skip[0] && h->cur_tag && h->cur_tag[0] && strstr(h->x3_skip, h->cur_tag)) a.x3 = 0;   // SGA_X3_SKIP
-  if (a.x3 && a.ksplit > 1 && (h->x3_mask & 4)) a.x3 = 0;           // bit 2: no x3 on split-K launches
-  if (a.x3 && a.ksplit <= 1 && (h->x3_mask & 8)) a.x3 = 0;          // bit 3: no x3 on unsplit launches
   const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
   if (a.ksplit > 1) { a.part = h->cur_part->p; a.slab = n_out; }
   sga_handle::ProfRec r;
@@ -728,7 +715,17 @@ int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, b
 
 // Synthesis branch given y_tilde: x_tilde = g_s(y_tilde), distortion and, with_grad, the
 // data-gradients back to y_tilde (sga.py:122-123, 150-154 and their part of sga.py:164).
-int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, hipStream_t st) {
+// `side`: called once, right before main-chain launch number `fork_at` (0 = the first one), to
+// enqueue whatever runs concurrently on the second stream.
+int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, hipStream_t st,
+                 int fork_at = 0, const std::function<int()>* side = nullptr) {
+  int launches = 0;
+  bool side_started = false;
+  auto tick = [&]() -> int {      // call before every main-chain launch
+    if (side && !side_started && launches >= fork_at) { side_started = true; SGACHK((*side)()); }
+    ++launches;
+    return SGA_OK;
+  };
   const int B = g.B;
   const float* cur = h->yt.p;
   int hh = g.yh, ww = g.yw;
@@ -741,27 +738,36 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   const bool fz = h->fused_gdn;
   for (int L = 0; L < 3; ++L) {
     Deferred d;
+    SGACHK(tick());
     h->cur_tag = kFwd[L];
     SGACHK(deconv_fwd(h, h->gs_f[L], h->gs_bias[L], cur, B, hh, ww, h->u[L].p, EPI_BIAS, st, fz ? &d : nullptr));
     hh *= 2; ww *= 2;
+    SGACHK(tick());
     h->cur_tag = kIgdn[L];
     SGACHK(gdn_fwd(h, h->gs_gdn_f[L], h->gs_beta[L], h->u[L].p, B, hh, ww, h->s[L].p, h->v[L].p, true, st, &d));
     cur = h->v[L].p;
   }
+  SGACHK(tick());
   h->cur_tag = "gs3.fwd";
   SGACHK(deconv_to3(h, h->gs_f[3], h->gs_bias[3], cur, B, hh, ww, g.H, g.W, h->xt.p, st));
+  SGACHK(tick());
   HIPCHK(h, launch_mse(x, h->xt.p, with_grad ? h->ctx : nullptr, B, g.H, g.W, g.Hp, g.Wp, h->sums,
                        with_grad ? h->gpad.p : nullptr, with_grad ? nullptr : h->xq.p, st));
-  if (!with_grad) return SGA_OK;
+  if (!with_grad) {
+    if (side && !side_started) SGACHK((*side)());
+    return SGA_OK;
+  }
   // hh,ww = 8yh,8yw: gradient w.r.t. v[2] from the bordered gradient image
   // gs3.bwd (the 5x5/2 conv of the 3-channel gradient image) is the prologue of igdn2.bwd when fused
   const bool conv3_fused = fz;
   if (!conv3_fused) {
+    SGACHK(tick());
     h->cur_tag = "gs3.bwd";
     SGACHK(conv_smallc(h, h->gs_b[3], nullptr, h->gpad.p, B, g.Hp, g.Wp, hh, ww, h->gA.p, st));
   }
   Deferred d;
   for (int L = 2; L >= 0; --L) {
+    SGACHK(tick());
     h->cur_tag = kIgdnB[L];
     if (L == 2 && conv3_fused)
       SGACHK(igdn_bwd(h, h->gs_gdn_b[L], nullptr, h->u[L].p, h->s[L].p, B, hh, ww, h->gB.p, st, nullptr,
@@ -769,12 +775,14 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
     else
       SGACHK(igdn_bwd(h, h->gs_gdn_b[L], h->gA.p, h->u[L].p, h->s[L].p, B, hh, ww, h->gB.p, st, &d));
     float* dst = (L == 0) ? h->g_yt_dist.p : h->gA.p;
+    SGACHK(tick());
     h->cur_tag = kBwd[L];
     d = Deferred();
     SGACHK(conv5s2(h, h->gs_b[L], nullptr, h->gB.p, B, hh, ww, hh / 2, ww / 2, dst, EPI_BIAS, nullptr, st,
                    (fz && L > 0) ? &d : nullptr));
     hh /= 2; ww /= 2;
   }
+  if (side && !side_started) SGACHK((*side)());
   h->cur_tag = "";
   return SGA_OK;
 }
@@ -785,7 +793,9 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
 // fork/join is recorded into the hipGraph when `st` is being captured).
 int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_grad,
                         hipStream_t st, bool density = false, bool do_synth = true) {
-  const bool fork = h->overlap && !h->profiling && do_synth;
+  // bf16x3 mode runs single-stream: with the hyper branch on a second stream its results were not
+  // reproducible run to run (the f32 mode is, and is the default)
+  const bool fork = h->overlap && !h->x3 && !h->profiling && do_synth;
   if (!fork) {
     h->cur_part = &h->part;
     SGACHK(hyper_branch(h, g, with_grad, st, density));
@@ -797,35 +807,28 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
   (void)hipStreamIsCapturing(st, &cs);
   hipEvent_t evf = cs == hipStreamCaptureStatusActive ? h->ev_fork_cap : h->ev_fork;
   hipEvent_t evj = cs == hipStreamCaptureStatusActive ? h->ev_join_cap : h->ev_join;
-  HIPCHK(h, hipEventRecord(evf, st));
-  HIPCHK(h, hipStreamWaitEvent(h->sB, evf, 0));
-  // Eager launches: the first kernel after a cross-stream wait was observed to read stale data
-  // (bf16x3 mode: k_factorized's output differed between identical runs while its input did not,
-  // scripts/eval_race.py + SGA_DEBUG_DUMP); a system-scope fence kernel with at least one workgroup
-  // per XCD between the wait and the first consumer made 21 of 21 2000-iteration runs identical.
-  // Inside a captured graph the same kernels made things worse, so they are eager-only.
-  const bool fence = h->fences && cs != hipStreamCaptureStatusActive;
-  if (fence) HIPCHK(h, launch_fence(h->sB));
-  if (h->dbg_delay_us > 0) HIPCHK(h, launch_spin(h->dbg_delay_us, h->sB));   // make the join "hot"
-  if (h->dbg_fork && h->dbg_it >= 0 && cs != hipStreamCaptureStatusActive)
-    HIPCHK(h, launch_check_iter(h->ctx, h->dbg_it, h->dbg_bad, h->sB));
-  h->cur_part = &h->partB;
-  int rc = hyper_branch(h, g, with_grad, h->sB, density);
-  h->cur_part = &h->part;
-  h->first_after_fork = true;
-  if (rc == SGA_OK) rc = synth_branch(h, g, x, with_grad, st);
-  h->first_after_fork = false;
+  bool forked = false;
+  const std::function<int()> side = [&]() -> int {
+    HIPCHK(h, hipEventRecord(evf, st));
+    HIPCHK(h, hipStreamWaitEvent(h->sB, evf, 0));
+    forked = true;
+    h->cur_part = &h->partB;
+    const char* tag = h->cur_tag;
+    const int rc = hyper_branch(h, g, with_grad, h->sB, density);
+    h->cur_part = &h->part;
+    h->cur_tag = tag;
+    return rc;
+  };
+  const int rc = synth_branch(h, g, x, with_grad, st, h->fork_at, &side);
   // always join, even on error, so a capture in progress is not left forked
-  const bool dbg = h->dbg_fork && h->dbg_it >= 0 && cs != hipStreamCaptureStatusActive;
-  if (dbg) (void)launch_set_int(h->dbg_bad + 8, h->dbg_it, h->sB);          // last op of the side branch
-  const hipError_t e1 = hipEventRecord(evj, h->sB);
-  const hipError_t e2 = hipStreamWaitEvent(st, evj, 0);
-  if (fence) (void)launch_fence(st);
-  if (dbg) (void)launch_check_int(h->dbg_bad + 8, h->dbg_it, h->dbg_bad + 1, st);   // first op after the join
-  SGACHK(rc);
-  HIPCHK(h, e1);
-  HIPCHK(h, e2);
-  return SGA_OK;
+  if (forked) {
+    const hipError_t e1 = hipEventRecord(evj, h->sB);
+    const hipError_t e2 = hipStreamWaitEvent(st, evj, 0);
+    SGACHK(rc);
+    HIPCHK(h, e1);
+    HIPCHK(h, e2);
+  }
+  return rc;
 }
 
 // one SGA evaluation: sample both latents (sga.py:86-98,111-121) then forward + backward
@@ -843,19 +846,7 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
   HIPCHK(h, launch_copy(h->yt.p, y_hat, (int64_t)(ny), st));
   HIPCHK(h, launch_copy(h->zt.p, z_hat, (int64_t)(nz), st));
   HIPCHK(h, launch_fill((float*)h->sums, 0.f, (int64_t)(sizeof(ImgSums) / sizeof(float)) * (g.B), st));
-  if (h->dbg_fork) {   // mark the main stream's position so the side stream's first kernel can check it
-    HIPCHK(h, launch_set_ctx(h->ctx, -777, 1, 0.f, 0.f, 0.f, 1.f, 0, st));
-    h->dbg_it = -777;
-  }
   SGACHK(rd_forward_backward(h, g, x, false, st));
-  if (h->dbg_fork) {
-    h->dbg_it = -1;
-    int bad = -1;
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(&bad, h->dbg_bad, sizeof(int), hipMemcpyDeviceToHost);
-    if (bad) fprintf(stderr, "[sga debug] eval: side stream started before the main stream's marker (%d)\n", bad);
-    (void)hipMemset(h->dbg_bad, 0, sizeof(int));
-  }
   if (metrics) {
     HIPCHK(h, launch_finalize_eval(h->sums, g.B, g.H, g.W, metrics, st));
     // sga.py:175-176; TF asserts H,W >= 176 for 5 scales: smaller images keep NaN
@@ -1062,15 +1053,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    // The side stream has NORMAL priority.  With a high-priority side stream the bf16x3 mode was not
-    // reproducible: identical runs differed in a few latents (eager launches: every run; graph
-    // replay: the eager evaluation's rate in 1 run of 4), while f32 mode, a single stream, or a
-    // normal-priority side stream were bit-reproducible in 88 of 88 runs (scripts/eval_race.py).
-    // Stream ordering itself was verified (SGA_DEBUG_FORK=1: the side stream never ran ahead of the
-    // main stream's marker).  The bf16x3 tiles use 78 KB of LDS per workgroup (f32: 47 KB); the
-    // working hypothesis is that waves of a lower-priority queue that get context-switched for
-    // the high-priority one are not restored exactly at that LDS size.  Throughput is identical
-    // with either priority (1.703 vs 1.702 img/s), so nothing is lost.
+    // The side stream has normal priority (a high-priority one measured the same throughput).
     int prio = 0;
     (void)lo; (void)hi;
     if (const char* pr = getenv("SGA_SIDE_PRIORITY")) prio = atoi(pr);   // experiments only
@@ -1096,24 +1079,10 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->split256 = !(env && env[0] == '0');
   env = getenv("SGA_BM256");
   h->bm256 = !(env && env[0] == '0');
+  env = getenv("SGA_FORK_AT");
+  if (env) h->fork_at = atoi(env);
   env = getenv("SGA_FUSED_GDN");
   h->fused_gdn = !(env && env[0] == '0');
-  env = getenv("SGA_X3_SKIP");
-  if (env) strncpy(h->x3_skip, env, sizeof(h->x3_skip) - 1);
-  env = getenv("SGA_X3_MASK");
-  if (env) h->x3_mask = atoi(env);
-  env = getenv("SGA_DEBUG_DELAY_US");
-  h->dbg_delay_us = env ? atoi(env) : 0;
-  env = getenv("SGA_NO_FENCES");
-  h->fences = !(env && env[0] == '1');
-  env = getenv("SGA_DEBUG_FORK");
-  if (env && env[0] == '1') {
-    h->dbg_fork = 1;
-    void* p = nullptr;
-    if (dev_alloc(h, &p, 256) != SGA_OK) return fail(SGA_ERR_NOMEM);
-    h->dbg_bad = (int*)p;
-    (void)hipMemset(p, 0, 256);
-  }
   env = getenv("SGA_NO_SPLITK");
   h->no_splitk = env && env[0] == '1';
   env = getenv("SGA_PROFILE_BY_LAYER");
@@ -1323,16 +1292,6 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
     char fn[512];
     snprintf(fn, sizeof(fn), "%s.%d", h->dump_path, h->dump_run++);
     if (FILE* f = fopen(fn, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
-  }
-  if (h->dbg_fork) {
-    int bad = -1;
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(&bad, h->dbg_bad, sizeof(int), hipMemcpyDeviceToHost);
-    int badj = -1;
-    (void)hipMemcpy(&badj, h->dbg_bad + 1, sizeof(int), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[sga debug] of %d iterations: side stream ahead of the fork %d, main stream ahead of the join %d\n",
-            n, bad, badj);
-    (void)hipMemset(h->dbg_bad, 0, 2 * sizeof(int));
   }
   return SGA_OK;
 }
