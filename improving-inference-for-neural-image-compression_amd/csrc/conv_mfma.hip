@@ -507,6 +507,7 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
     case 32: tn = 1; tm = 1; wm = 4; wn = 1; break;
   }
   if (a.bm == 256) wm = 4;
+  if (a.bm == 64) tm = 1;
   snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%s>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
            a.smallc ? "true" : "false", (a.x3 && !a.smallc && bn != 32) ? "true" : "false");
 }
@@ -529,6 +530,10 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
   const int bn = a.Npad / a.ntiles_n;
   switch (bn) {
     case 192:
+      if (a.bm == 64) {
+        if (a.smallc || a.pro != PRO_NONE || a.x3) return (int)hipErrorInvalidValue;
+        return launch_inst<1, 3, 2, 2, PRO_NONE, false>(a, stream);
+      }
       if (a.bm == 256) {
         if (a.smallc || a.pro != PRO_NONE || a.x3) return (int)hipErrorInvalidValue;
         return launch_inst<2, 3, 4, 2, PRO_NONE, false>(a, stream);

@@ -51,15 +51,15 @@ __device__ __forceinline__ float sgnf(float t) { return (t > 0.f) - (t < 0.f); }
 //   v_tilde = floor*s0 + ceil*s1
 // floor/ceil carry no gradient; clip passes gradient inside [-1+eps, 1-eps].
 // ------------------------------------------------------------------------------------------
-__global__ void k_sample(const float* __restrict__ v, const float* __restrict__ u,
+__device__ __forceinline__ void sample_range(const float* __restrict__ v, const float* __restrict__ u,
                          const StepCtx* __restrict__ ctx, int stream_id, float* __restrict__ vt,
                          float* __restrict__ dvt, int64_t n, int mode,
-                         const int* __restrict__ img_ids, int64_t per_img) {
+                         const int* __restrict__ img_ids, int64_t per_img, int bid, int nblk) {
   const float T = ctx->T;
   const int it = ctx->it;
   const unsigned k0 = ctx->seed_lo, k1 = ctx->seed_hi;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
-       idx += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t idx = (int64_t)bid * blockDim.x + threadIdx.x; idx < n;
+       idx += (int64_t)nblk * blockDim.x) {
     float u0, u1;
     if (u) {
       u0 = u[2 * idx];
@@ -108,6 +108,24 @@ __global__ void k_sample(const float* __restrict__ v, const float* __restrict__ 
       dvt[idx] = (ce - fl) * s0 * s1 * dd;
     }
   }
+}
+
+__global__ void k_sample(const float* __restrict__ v, const float* __restrict__ u,
+                         const StepCtx* __restrict__ ctx, int stream_id, float* __restrict__ vt,
+                         float* __restrict__ dvt, int64_t n, int mode,
+                         const int* __restrict__ img_ids, int64_t per_img) {
+  sample_range(v, u, ctx, stream_id, vt, dvt, n, mode, img_ids, per_img, blockIdx.x, gridDim.x);
+}
+
+// y (stream 0) and z (stream 1) in one launch: blocks [0, gy) relax y, the rest z
+__global__ void k_sample_yz(const float* __restrict__ y, float* __restrict__ yt, float* __restrict__ dyt,
+                            int64_t ny, const float* __restrict__ z, float* __restrict__ zt,
+                            float* __restrict__ dzt, int64_t nz, const StepCtx* __restrict__ ctx, int mode,
+                            const int* __restrict__ img_ids, int B, int gy) {
+  if ((int)blockIdx.x < gy)
+    sample_range(y, nullptr, ctx, 0, yt, dyt, ny, mode, img_ids, ny / B, blockIdx.x, gy);
+  else
+    sample_range(z, nullptr, ctx, 1, zt, dzt, nz, mode, img_ids, nz / B, blockIdx.x - gy, gridDim.x - gy);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -513,6 +531,31 @@ __global__ void k_adam_latent(float* __restrict__ p, const float* __restrict__ g
   }
 }
 
+// y and z in one launch: blocks [0, gy) update y, the rest z (same arithmetic as k_adam_latent)
+__global__ void k_adam_latent_yz(float* __restrict__ py, const float* __restrict__ gay, const float* __restrict__ gby,
+                                 const float* __restrict__ jy, float* __restrict__ my, float* __restrict__ vy,
+                                 int64_t ny, float* __restrict__ pz, const float* __restrict__ gaz,
+                                 const float* __restrict__ gbz, const float* __restrict__ jz,
+                                 float* __restrict__ mz, float* __restrict__ vz, int64_t nz,
+                                 const StepCtx* __restrict__ ctx, int gy) {
+  const float lr_t = ctx->lr_t;
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+  const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999);
+  const bool isy = (int)blockIdx.x < gy;
+  float* p = isy ? py : pz; const float* ga = isy ? gay : gaz; const float* gb = isy ? gby : gbz;
+  const float* jac = isy ? jy : jz; float* m = isy ? my : mz; float* v = isy ? vy : vz;
+  const int64_t n = isy ? ny : nz;
+  const int bid = isy ? blockIdx.x : blockIdx.x - gy, nblk = isy ? gy : gridDim.x - gy;
+  for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < n; i += (int64_t)nblk * blockDim.x) {
+    float s = ga[i];
+    if (gb) s += gb[i];
+    const float g = s * jac[i];
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam_update(pp, g, mm, vv, lr_t, b1, omb1, b2, omb2, eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, int64_t n, float lr_t, float b1, float omb1,
                        float b2, float omb2, float eps) {
@@ -578,8 +621,9 @@ __global__ void k_check_int(const int* __restrict__ p, int expected, int* __rest
   if (*p != expected) atomicAdd(bad, 1);
 }
 
-__global__ void k_finalize_step(ImgSums* sums, const StepCtx* __restrict__ ctx, int B, int H,
-                                int W, float* scalars, float* psnr, float* trace) {
+__global__ void k_finalize_step(ImgSums* sums, StepCtx* __restrict__ ctx, int B, int H,
+                                int W, float* scalars, float* psnr, float* trace,
+                                const float* __restrict__ Ttab, const float* __restrict__ lrtab) {
   if (threadIdx.x != 0) return;
   const double npx = (double)H * W;
   const double ls = ctx->loss_scale;
@@ -602,6 +646,13 @@ __global__ void k_finalize_step(ImgSums* sums, const StepCtx* __restrict__ ctx, 
   if (trace) {
     float* row = trace + (size_t)ctx->it * 4;
     row[0] = loss; row[1] = train_mse; row[2] = train_bpp; row[3] = (float)(ps / B);
+  }
+  // last kernel of the iteration: set the step context of the next one (it, T = Ttab[it], lr_t =
+  // lrtab[it]; sga.py:211, adam.py:40-42), so that no separate launch has to do it
+  if (Ttab) {
+    const int it = ctx->it + 1;
+    ctx->it = it;
+    if (it < ctx->its) { ctx->T = Ttab[it]; ctx->lr_t = lrtab[it]; }
   }
 }
 
@@ -811,10 +862,27 @@ int launch_check_int(const int* p, int expected, int* bad, hipStream_t s) {
   LAUNCH_RET();
 }
 
-int launch_finalize_step(ImgSums* sums, const StepCtx* ctx, int B, int H, int W, float* scalars,
-                         float* psnr, float* trace, hipStream_t s) {
+int launch_finalize_step(ImgSums* sums, StepCtx* ctx, int B, int H, int W, float* scalars,
+                         float* psnr, float* trace, hipStream_t s, const float* Ttab, const float* lrtab) {
   hipLaunchKernelGGL(k_finalize_step, dim3(1), dim3(64), 0, s, sums, ctx, B, H, W, scalars, psnr,
-                     trace);
+                     trace, Ttab, lrtab);
+  LAUNCH_RET();
+}
+
+int launch_sample_yz(const float* y, float* yt, float* dyt, int64_t ny, const float* z, float* zt, float* dzt,
+                     int64_t nz, const StepCtx* ctx, int mode, const int* img_ids, int B, hipStream_t s) {
+  const int gy = grid_for(ny), gz = grid_for(nz);
+  hipLaunchKernelGGL(k_sample_yz, dim3(gy + gz), dim3(256), 0, s, y, yt, dyt, ny, z, zt, dzt, nz, ctx, mode,
+                     img_ids, B, gy);
+  LAUNCH_RET();
+}
+
+int launch_adam_latent_yz(float* py, const float* gay, const float* gby, const float* jy, float* my, float* vy,
+                          int64_t ny, float* pz, const float* gaz, const float* gbz, const float* jz,
+                          float* mz, float* vz, int64_t nz, const StepCtx* ctx, hipStream_t s) {
+  const int gy = grid_for(ny), gz = grid_for(nz);
+  hipLaunchKernelGGL(k_adam_latent_yz, dim3(gy + gz), dim3(256), 0, s, py, gay, gby, jy, my, vy, ny, pz, gaz,
+                     gbz, jz, mz, vz, nz, ctx, gy);
   LAUNCH_RET();
 }
 

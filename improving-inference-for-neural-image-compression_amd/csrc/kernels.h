@@ -63,8 +63,16 @@ int launch_advance_ctx(StepCtx* ctx, const float* Ttab, const float* lrtab, hipS
 
 // consume + zero the per-image sums.  scalars[3] = {rd_loss, train_mse, train_bpp}; psnr[B];
 // trace row [it][4] (if trace != null).  Any output may be null.
-int launch_finalize_step(ImgSums* sums, const StepCtx* ctx, int B, int H, int W, float* scalars,
-                         float* psnr, float* trace, hipStream_t s);
+// Ttab / lrtab != null: also advance the step context to the next iteration (it += 1, T, lr_t)
+int launch_finalize_step(ImgSums* sums, StepCtx* ctx, int B, int H, int W, float* scalars,
+                         float* psnr, float* trace, hipStream_t s, const float* Ttab = nullptr,
+                         const float* lrtab = nullptr);
+// the y and z relaxations / Adam updates of one SGA iteration in one launch each (Philox noise only)
+int launch_sample_yz(const float* y, float* yt, float* dyt, int64_t ny, const float* z, float* zt, float* dzt,
+                     int64_t nz, const StepCtx* ctx, int mode, const int* img_ids, int B, hipStream_t s);
+int launch_adam_latent_yz(float* py, const float* gay, const float* gby, const float* jy, float* my, float* vy,
+                          int64_t ny, float* pz, const float* gaz, const float* gbz, const float* jz,
+                          float* mz, float* vz, int64_t nz, const StepCtx* ctx, hipStream_t s);
 // metrics[B][7] = {mse, psnr, msssim(=nan here), msssim_db, est_bpp, est_y_bpp, est_z_bpp}
 int launch_finalize_eval(ImgSums* sums, int B, int H, int W, float* metrics, hipStream_t s);
 

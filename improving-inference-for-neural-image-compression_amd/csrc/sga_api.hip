@@ -101,6 +101,7 @@ struct sga_handle {
   float run_lambda = 0.f, run_loss_scale = 1.f; uint64_t run_seed = 0;
   bool split256 = true;            // split-K also for a single-phase launch of exactly 256 tiles (SGA_SPLIT256=0: off)
   bool fused_gdn = true;           // gdn_fused.hip instead of the stand-alone GDN launches (SGA_FUSED_GDN=0: off)
+  int bm64_max = 256;              // 64-row tiles when the 128-row grid has at most this many blocks (SGA_BM64_MAX; 0 = off)
   bool bm256 = true;               // 256-row 8-wave tile for big unsplit f32 launches (SGA_BM256=0: off)
   int fork_at = 0;                 // main-chain launch index at which the hyper branch is forked (SGA_FORK_AT)
   int dbg_it = -1;                 // iteration being enqueued (SGA_DEBUG_DUMP)
@@ -203,6 +204,13 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
       (long long)a.nphase * a.tiles_per_phase * a.ntiles_n >= 1024) {
     a.bm = 256;
     a.tiles_per_phase = (a.tiles_per_phase + 1) / 2;
+  }
+  // 64-row tile (4 waves, 3 workgroups/CU) for launches whose 128-row grid under-fills the chip
+  if (h->bm64_max > 0 && !h->x3 && !a.smallc && a.pro == PRO_NONE && a.Npad / a.ntiles_n == 192 &&
+      (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RELU_MASK) &&
+      (long long)a.nphase * a.tiles_per_phase * a.ntiles_n <= h->bm64_max) {
+    a.bm = 64;
+    a.tiles_per_phase = cdiv(a.B * a.Hg * a.Wg, 64);
   }
   a.ksplit = pick_ksplit(h, a);
   if (defer && a.epi != EPI_BIAS) return SGA_ERR_BAD_ARG;   // the consumer applies "+ bias" only
@@ -835,8 +843,13 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
 int sga_step_core(sga_handle* h, const Geom& g, const float* x, const float* y, const float* z,
                   const float* u_y, const float* u_z, hipStream_t st) {
   const int64_t ny = (int64_t)g.B * g.yh * g.yw * h->C, nz = (int64_t)g.B * g.zh * g.zw * h->C;
-  HIPCHK(h, launch_sample(z, u_z, h->ctx, 1, h->zt.p, h->dzt.p, nz, st, h->relax, h->img_ids, nz / g.B));
-  HIPCHK(h, launch_sample(y, u_y, h->ctx, 0, h->yt.p, h->dyt.p, ny, st, h->relax, h->img_ids, ny / g.B));
+  if (!u_y && !u_z) {
+    HIPCHK(h, launch_sample_yz(y, h->yt.p, h->dyt.p, ny, z, h->zt.p, h->dzt.p, nz, h->ctx, h->relax, h->img_ids,
+                               g.B, st));
+  } else {
+    HIPCHK(h, launch_sample(z, u_z, h->ctx, 1, h->zt.p, h->dzt.p, nz, st, h->relax, h->img_ids, nz / g.B));
+    HIPCHK(h, launch_sample(y, u_y, h->ctx, 0, h->yt.p, h->dyt.p, ny, st, h->relax, h->img_ids, ny / g.B));
+  }
   return rd_forward_backward(h, g, x, true, st);
 }
 
@@ -1079,6 +1092,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->split256 = !(env && env[0] == '0');
   env = getenv("SGA_BM256");
   h->bm256 = !(env && env[0] == '0');
+  env = getenv("SGA_BM64_MAX");
+  if (env) h->bm64_max = atoi(env);
   env = getenv("SGA_FORK_AT");
   if (env) h->fork_at = atoi(env);
   env = getenv("SGA_FUSED_GDN");
@@ -1238,15 +1253,16 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
   const int C = h->C;
   const int64_t ny = (int64_t)B * g.yh * g.yw * C, nz = (int64_t)B * g.zh * g.zw * C;
   // other entry points (sga_step_grads, sga_eval) may have used the step context and the sums
-  HIPCHK(h, launch_set_ctx(h->ctx, h->run_it - 1, its, 0.f, 0.f, h->run_lambda, h->run_loss_scale, h->run_seed, st));
+  // the step context of the first of these iterations; k_finalize_step advances it from then on
+  HIPCHK(h, launch_set_ctx(h->ctx, h->run_it, its, h->hT[h->run_it], h->hLr[h->run_it], h->run_lambda,
+                           h->run_loss_scale, h->run_seed, st));
   HIPCHK(h, launch_fill((float*)h->sums, 0.f, (int64_t)(sizeof(ImgSums) / sizeof(float)) * (B), st));
 
   auto enqueue_step = [&](hipStream_t s) -> int {
-    HIPCHK(h, launch_advance_ctx(h->ctx, h->Ttab.p, h->lrtab.p, s));
     SGACHK(sga_step_core(h, g, h->xin.p, h->y.p, h->z.p, nullptr, nullptr, s));
-    HIPCHK(h, launch_adam_latent(h->y.p, h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, h->my.p, h->vy.p, ny, h->ctx, s));
-    HIPCHK(h, launch_adam_latent(h->z.p, h->g_zt_hs.p, h->g_zt_eb.p, h->dzt.p, h->mz.p, h->vz.p, nz, h->ctx, s));
-    HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, nullptr, nullptr, h->trace.p, s));
+    HIPCHK(h, launch_adam_latent_yz(h->y.p, h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, h->my.p, h->vy.p, ny,
+                                    h->z.p, h->g_zt_hs.p, h->g_zt_eb.p, h->dzt.p, h->mz.p, h->vz.p, nz, h->ctx, s));
+    HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, nullptr, nullptr, h->trace.p, s, h->Ttab.p, h->lrtab.p));
     if (h->dump && h->dbg_it >= 0) {
       unsigned long long* o = h->dump + (size_t)h->dbg_it * 16;
       const float* bufs[12] = {h->yt.p, h->zt.p, h->u[0].p, h->v[0].p, h->u[1].p, h->u[2].p, h->g_yt_dist.p,
