@@ -88,3 +88,106 @@ def test_bits_back_step_at_kodak_size(H, W, gpu_out_dir):
     report(gpu_out_dir, test="config_bb_step", H=H, W=W, gy=ey, gzml=ez)
     assert ey < 1e-4 and ez < 2e-4, (ey, ez)
     codec.close()
+
+
+def test_base_compress_at_cfg1_shape(gpu_out_dir):
+    """cfg 1 as BASELINE.json names it: mbt2018.py compress (estimated-rate path, mbt2018.py:64-81,
+    167-180) on a 256x256 image at num_filters=192, with non-zero medians (tfc `quantiles[:,0,1]`), vs
+    the oracle."""
+    from sga_amd.codec import SGACodec, metrics_to_dict
+    C, H, W = 192, 256, 256
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    codec, orc = SGACodec(w, C, 1, H, W), SGAOracle(w)
+    x = np.random.RandomState(12).rand(1, H, W, 3).astype(np.float32)
+    med = np.linspace(-0.45, 0.45, C).astype(np.float32)
+    y_hat, z_hat, met = codec.base_compress(x, medians=med)
+    yo, zo, want = orc.base_compress(x, medians=med)
+    # a rounding decision can flip where y - mu sits within float32 noise of a .5 tie
+    dy = np.abs(y_hat.cpu().numpy() - yo.numpy()) > 1e-3
+    dz = np.abs(z_hat.cpu().numpy() - zo.numpy()) > 1e-3
+    got = metrics_to_dict(met)
+    report(gpu_out_dir, test="base_compress_cfg1", flipped_y=float(dy.mean()), flipped_z=float(dz.mean()),
+           bpp=got["est_bpp"].tolist(), bpp_ref=want["est_bpp"].tolist(), psnr=got["psnr"].tolist(),
+           psnr_ref=want["psnr"].tolist())
+    assert dy.mean() < 1e-3 and dz.mean() < 5e-3
+    assert np.allclose(got["est_bpp"], want["est_bpp"], rtol=2e-3)
+    assert np.allclose(got["psnr"], want["psnr"], atol=0.02)
+    # z_hat really is centred on the medians (not on the integers)
+    frac = z_hat.cpu().numpy() - med
+    assert np.abs(frac - np.round(frac)).max() < 1e-4
+    codec.close()
+
+
+def _properties_of_full_run(codec, x, lmbda, its, gpu_out_dir, tag):
+    """Oracle-free properties of a complete run (the oracle needs minutes per image at these sizes):
+    bit-reproducible; the returned metrics are the evaluation of the returned latents; rate fields add
+    up; latents are integers; every image's R-D objective improves on its starting point."""
+    from sga_amd.codec import metrics_to_dict
+    a = codec.run(x, lmbda, its=its, seed=5)
+    b = codec.run(x, lmbda, its=its, seed=5)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2][:, [0, 1, 4, 5, 6]], b[2][:, [0, 1, 4, 5, 6]])
+    y_hat, z_hat, met, _ = a
+    assert torch.equal(y_hat, torch.round(y_hat)) and torch.equal(z_hat, torch.round(z_hat))
+    m = metrics_to_dict(met)
+    again = metrics_to_dict(codec.evaluate(x, y_hat, z_hat))
+    for k in ("mse", "psnr", "est_bpp", "est_y_bpp", "est_z_bpp"):
+        assert np.array_equal(m[k], again[k]), k
+    assert np.allclose(m["est_bpp"], m["est_y_bpp"] + m["est_z_bpp"], rtol=1e-6)
+    assert np.isfinite(m["msssim"]).all() and (m["msssim"] <= 1).all()
+    m0 = metrics_to_dict(codec.run(x, lmbda, its=0)[2])
+    j, j0 = lmbda * m["mse"] + m["est_bpp"], lmbda * m0["mse"] + m0["est_bpp"]
+    report(gpu_out_dir, test="full_run_properties", config=tag, its=its, objective_before=j0.tolist(),
+           objective_after=j.tolist(), est_bpp=m["est_bpp"].tolist(), psnr=m["psnr"].tolist())
+    assert (j < j0).all(), (j, j0)
+
+
+def test_full_run_cfg3_kodak_batch():
+    """cfg 3: the complete 2000-step run on a 3-image batch of Kodak-shaped images (24 images over 8
+    GPUs), num_filters=192."""
+    from sga_amd.codec import SGACodec
+    C, B, H, W = 192, 3, 512, 768
+    codec = SGACodec(sga_amd.make_synthetic_weights(C, seed=0), C, B, H, W)
+    x = np.random.RandomState(21).rand(B, H, W, 3).astype(np.float32)
+    _properties_of_full_run(codec, x, 0.01, 2000, os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out"),
+                            "cfg3 3x512x768 C=192")
+    codec.close()
+
+
+def test_full_run_cfg4_tecnick():
+    """cfg 4: the complete 2000-step run at 1200x1200, num_filters=256, lambda=0.08 (ragged: 75x75
+    latents, mu/sigma cropped from 76x76, sga.py:126-128)."""
+    from sga_amd.codec import SGACodec
+    C, B, H, W = 256, 1, 1200, 1200
+    codec = SGACodec(sga_amd.make_synthetic_weights(C, seed=0), C, B, H, W)
+    x = np.random.RandomState(22).rand(B, H, W, 3).astype(np.float32)
+    _properties_of_full_run(codec, x, 0.08, 2000, os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out"),
+                            "cfg4 1x1200x1200 C=256")
+    codec.close()
+
+
+def test_full_bits_back_run_cfg5_kodak():
+    """cfg 5: bb_sga.py's complete two-stage run (2000 + 2000 iterations, bb_sga.py:199-276) on a
+    Kodak-shaped image: reproducible, 8 metric fields consistent (est_bpp = y + z - back), y_hat integer,
+    stage 2 lowers the rate objective it optimises."""
+    from sga_amd.codec import SGACodec, metrics_to_dict
+    C, B, H, W = 192, 1, 512, 768
+    w = dict(sga_amd.make_synthetic_weights(C, seed=0, bb=True))
+    # the untrained synthetic h_a emits |z_mean|, |z_logvar| ~ 20 at this image size, where exp(.) of the
+    # predicted log-scale overflows float32 (here as it would in TF); a trained model keeps them O(1)
+    w["ha.k2"] = (w["ha.k2"] * 0.05).astype(np.float32)
+    codec = SGACodec(w, C, B, H, W, bits_back=True)
+    x = np.random.RandomState(23).rand(B, H, W, 3).astype(np.float32)
+    a = codec.bb_run(x, 0.01, its=2000, r_its=2000, seed=4, trace=True)
+    b = codec.bb_run(x, 0.01, its=2000, r_its=2000, seed=4, trace=True)
+    assert torch.isfinite(a[1]).all()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    y_hat, zml, met, tr1, tr2 = a
+    assert torch.equal(y_hat, torch.round(y_hat))
+    m = metrics_to_dict(met)
+    assert np.isfinite(m["est_bpp"]).all() and np.isfinite(m["psnr"]).all() and np.isfinite(m["est_bpp_back"]).all()
+    assert np.allclose(m["est_bpp"], m["est_y_bpp"] + m["est_z_bpp"] - m["est_bpp_back"], rtol=1e-5, atol=1e-6)
+    tr1, tr2 = tr1.cpu().numpy(), tr2.cpu().numpy()
+    assert np.isfinite(tr1).all() and np.isfinite(tr2[:, :3]).all()      # stage 2 has no distortion term: its psnr column is inf
+    assert tr1[-50:, 0].mean() < tr1[:50, 0].mean()          # stage 1: rd_loss falls
+    assert tr2[-50:, 2].mean() < tr2[:50, 2].mean()          # stage 2: train_bpp falls
+    codec.close()
