@@ -171,6 +171,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
   int smax = a.nsplit[0];
   if (a.s_out == 2) smax = max(max(a.nsplit[0], a.nsplit[1]), max(a.nsplit[2], a.nsplit[3]));
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // beta and the conv bias depend on the piece's column only: KC float4 each, loaded ONCE up front.  A load
+  // inside the epilogue would make every piece wait (vmcnt is in-order and counts stores) for the stores
+  // of the pieces before it.
+  f32x4 betav[KC], biasv[KC];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    betav[kc] = (MODE != GDN_IGDN_BWD) ? ld4(a.beta + pc * 4 + kc * CW * 4) : zero4;
+    biasv[kc] = (PRO != GDN_PRO_CONV3 && a.bias) ? ld4(a.bias + pc * 4 + kc * CW * 4) : zero4;
+  }
   f32x4 e1[NF], e2[MODE == GDN_IGDN_BWD ? NF : 1];
 #pragma unroll
   for (int kr = 0; kr < KR; ++kr) {
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
       }
       if (a.bias) {
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) t[kc] += ld4(a.bias + pc * 4 + kc * CW * 4);
+        for (int kc = 0; kc < KC; ++kc) t[kc] += biasv[kc];
       }
     }
 #pragma unroll
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
         if constexpr (MODE == GDN_IGDN_BWD) {
           *reinterpret_cast<f32x4*>(a.out + e) = e1[k] + e2[k] * n;
         } else {
-          const f32x4 nb = n + ld4(a.beta + pc * 4 + kc * CW * 4);
+          const f32x4 nb = n + betav[kc];
           f32x4 sq, v;
 #pragma unroll
           for (int x = 0; x < 4; ++x) sq[x] = sqrtf(nb[x]);
