@@ -65,7 +65,13 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2& h, u32x2& m, u32x2&
   l.y = cvt_pk_bf16(r2 - bf16_lo(m.y), r3 - bf16_hi(m.y));
 }
 
-template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3>
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// POST = 1 (256-row tile, BN = C = 192 only): the IGDN that follows the transposed convolution
+// (nn_models.py:48-59) runs as a post-phase of the SAME launch, on the tile while it is on chip:
+// u = acc + bias goes to LDS, n = gamma . u^2 is a second MFMA contraction out of LDS, s = sqrt(n + beta),
+// v = u * s; u, s and v leave in whole 16-byte row pieces.  See the block after the K loop.
+template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3, int POST = 0>
 __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -77,7 +83,10 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   constexpr int CPITCH = TN * 32 + 4;         // epilogue staging pitch (floats) per wave row
   constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (BM + BN) * LDK;
   constexpr int EPI_FLOATS = WM * WN * 32 * CPITCH;
-  constexpr int LDS_FLOATS = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
+  constexpr int POST_FLOATS = POST ? (128 * (BN + 4) + 2 * BN * LDK) : 0;
+  constexpr int LDS_FLOATS0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
+  constexpr int LDS_FLOATS = LDS_FLOATS0 > POST_FLOATS ? LDS_FLOATS0 : POST_FLOATS;
+  static_assert(!POST || (BM == 256 && BN == 192 && NT == 512 && !X3 && !SMALLC && PRO == PRO_NONE), "post-phase instance");
   constexpr int PBX = X3 ? (BN * 12) / NT : 1;     // 16-byte pieces of the 3-plane weight tile per thread
   static_assert(!X3 || (BN * 12) % NT == 0, "x3 loader mismatch");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -316,6 +325,113 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   // ---- epilogue -------------------------------------------------------------------------------
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
   const int half = lane >> 5, col = lane & 31;
+  if constexpr (POST) {
+    // ---- fused IGDN (two halves of 128 tile rows; all 8 waves multiply, one barrier per K-step) ----
+    constexpr int C = BN, TP = C + 4;
+    float* const Tt = smem;                          // [128][TP]: u of the current half
+    float* const Bq = smem + 128 * TP;               // [2][C][LDK]: gamma K-chunks, double-buffered
+    const int m4 = wid >> 1, n2 = wid & 1;           // post-phase wave grid 4 (rows) x 2 (cols): 32 x 96 each
+    float bias_c[TN], beta_c[TN];                    // per-lane columns: before any store is in flight
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      bias_c[tn] = a.bias ? a.bias[(wn * TN + tn) * 32 + col] : 0.f;
+      beta_c[tn] = a.post_beta[(n2 * TN + tn) * 32 + col];
+    }
+    // gamma chunk loader: C rows x 32 floats = C*8 float4 over 512 threads
+    constexpr int QB = C * 8 / NT;                   // 3
+    f32x4 rq[QB];
+    auto load_q = [&](int kc) {
+#pragma unroll
+      for (int p = 0; p < QB; ++p) rq[p] = ld4(a.post_w + (size_t)(p * RPP + lrow) * C + kc * 32 + chunk * 4);
+    };
+    auto store_q = [&](int buf) {
+#pragma unroll
+      for (int p = 0; p < QB; ++p)
+        *reinterpret_cast<f32x4*>(&Bq[buf * (C * LDK) + (p * RPP + lrow) * LDK + chunk * 4]) = rq[p];
+    };
+    lds_barrier();                                   // main-loop LDS is dead from here on
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      load_q(0);
+      if ((wm >> 1) == h) {                          // the 4 waves that own these 128 rows: u = acc + bias
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+              Tt[((wm & 1) * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * TP + (wn * TN + tn) * 32 + col] =
+                  acc[tm][tn][reg] + bias_c[tn];
+      }
+      store_q(0);
+      load_q(1);
+      lds_barrier();
+      f32x16 acc2[TN];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[tn][r] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < C / 32; ++kc) {
+        if (kc + 1 < C / 32) store_q((kc + 1) & 1);
+        if (kc + 2 < C / 32) load_q(kc + 2);
+        const float* Bs2 = Bq + (kc & 1) * (C * LDK);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 af = *reinterpret_cast<const f32x4*>(&Tt[(m4 * 32 + col) * TP + kc * 32 + q * 8 + koff]);
+          af = af * af;
+          f32x4 bf2[TN];
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            bf2[tn] = *reinterpret_cast<const f32x4*>(&Bs2[((n2 * TN + tn) * 32 + col) * LDK + q * 8 + koff]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc2[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r], bf2[tn][r], acc2[tn], 0, 0, 0);
+        }
+        lds_barrier();
+      }
+      // ---- epilogue of the half: this wave's private 32 x 96 block of the tile -------------------
+      float* const cb = Tt + (m4 * 32 + 4 * half) * TP + n2 * TN * 32 + col;     // C-layout base
+      const int er = lane >> 3, ec = lane & 7;                                    // row-major: 8 lanes per row
+      const float* const rb0 = Tt + (m4 * 32 + er) * TP + n2 * TN * 32 + ec * 4;
+      long long px[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) px[k] = rowpix[h * 128 + m4 * 32 + er + 8 * k];
+      auto emit = [&](float* dst) {                  // the block, row-major, 16 bytes per lane
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rb0 + k * 8 * TP + j * 32);
+            if (px[k] >= 0)
+              *reinterpret_cast<f32x4*>(dst + (size_t)px[k] * a.out_cs + a.out_coff + n2 * TN * 32 + j * 32 + ec * 4) = v;
+          }
+      };
+      emit(a.out);                                   // u
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          float* e = cb + ((reg & 3) + 8 * (reg >> 2)) * TP + tn * 32;
+          *e = *e * sqrtf(acc2[tn][reg] + beta_c[tn]);          // v = u * s, in place
+        }
+      __builtin_amdgcn_wave_barrier();
+      emit(a.post_v);                                // v
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          cb[((reg & 3) + 8 * (reg >> 2)) * TP + tn * 32] = sqrtf(acc2[tn][reg] + beta_c[tn]);   // s (recomputed: registers are short)
+      __builtin_amdgcn_wave_barrier();
+      emit(a.post_s);                                // s
+      lds_barrier();                                 // the tile is rewritten by the next half
+    }
+    return;
+  }
   if (a.epi == EPI_SHUFFLE3 && a.ksplit <= 1) {
     // columns n = (py*2+px)*3 + c of a combined-phase C->3 transposed conv (scalar scatter)
     if (TN == 1 && wn == 0) {
@@ -439,17 +555,18 @@ __global__ void splitk_reduce_kernel(const ReduceArgs r) {
   }
 }
 
-template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3 = false>
+template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3 = false, int POST = 0>
 int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (BM + BN) * LDK;
   constexpr int EPI_FLOATS = WM * WN * 32 * (TN * 32 + 4);
-  const size_t lds = (size_t)(MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS) * sizeof(float) +
-                     BM * sizeof(long long);
+  constexpr int POST_FLOATS = POST ? (128 * (BN + 4) + 2 * BN * LDK) : 0;
+  constexpr int F0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
+  const size_t lds = (size_t)(F0 > POST_FLOATS ? F0 : POST_FLOATS) * sizeof(float) + BM * sizeof(long long);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC, X3>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC, X3, POST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -459,7 +576,7 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
     for (int p = 0; p < a.nphase; ++p) grid += a.tiles_per_phase * a.ntiles_n * a.nsplit[p];
   }
   if (grid <= 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC, X3>), dim3(grid), dim3(NT), lds,
+  hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC, X3, POST>), dim3(grid), dim3(NT), lds,
                      stream, a);
   return (int)hipGetLastError();
 }
@@ -508,6 +625,10 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
   }
   if (a.bm == 256) wm = 4;
   if (a.bm == 64) tm = 1;
+  if (a.post) {
+    snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,0,false,false,1>", tm, tn, wm, wn);
+    return;
+  }
   snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%s>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
            a.smallc ? "true" : "false", (a.x3 && !a.smallc && bn != 32) ? "true" : "false");
 }
@@ -536,6 +657,11 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
       }
       if (a.bm == 256) {
         if (a.smallc || a.pro != PRO_NONE || a.x3) return (int)hipErrorInvalidValue;
+        if (a.post) {
+          if (a.ksplit > 1 || a.epi != EPI_BIAS || a.Cout != 192 || a.out_coff != 0 || a.out_cs != 192)
+            return (int)hipErrorInvalidValue;
+          return launch_inst<2, 3, 4, 2, PRO_NONE, false, false, 1>(a, stream);
+        }
         return launch_inst<2, 3, 4, 2, PRO_NONE, false>(a, stream);
       }
       return launch_pro<2, 3, 2, 2>(a, stream);

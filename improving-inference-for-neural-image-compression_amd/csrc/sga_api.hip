@@ -100,6 +100,7 @@ struct sga_handle {
   int run_B = 0, run_H = 0, run_W = 0, run_its = -1, run_it = 0;   // sga_run_begin/steps state
   float run_lambda = 0.f, run_loss_scale = 1.f; uint64_t run_seed = 0;
   bool split256 = true;            // split-K also for a single-phase launch of exactly 256 tiles (SGA_SPLIT256=0: off)
+  bool fused_post = true;          // IGDN as the post-phase of the producing convolution launch (SGA_FUSED_POST=0: off)
   bool fused_gdn = true;           // gdn_fused.hip instead of the stand-alone GDN launches (SGA_FUSED_GDN=0: off)
   int bm64_max = 256;              // 64-row tiles when the 128-row grid has at most this many blocks (SGA_BM64_MAX; 0 = off)
   bool bm256 = true;               // 256-row 8-wave tile for big unsplit f32 launches (SGA_BM256=0: off)
@@ -195,8 +196,15 @@ struct Deferred {
   const float* bias = nullptr;
 };
 
+// An IGDN to run as the post-phase of the convolution that produces its input (conv_mfma.hip, POST = 1):
+// possible when the launch is an unsplit 256-row-tile one with all C = 192 channels in a tile.
+struct PostGdn {
+  const float* gamma_w = nullptr; const float* beta = nullptr; float* s_out = nullptr; float* v_out = nullptr;
+  bool fused = false;        // out: the convolution launch did the IGDN as well
+};
+
 // every MFMA convolution goes through here (so it can be timed)
-int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nullptr) {
+int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nullptr, PostGdn* post = nullptr) {
   // 256-row tile (8 waves): each weight byte feeds twice the MFMAs; only for big unsplit f32 launches
   a.bm = 128;
   if (h->bm256 && !h->x3 && !a.smallc && a.pro == PRO_NONE && a.Npad / a.ntiles_n == 192 &&
@@ -214,6 +222,14 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   }
   a.ksplit = pick_ksplit(h, a);
   if (defer && a.epi != EPI_BIAS) return SGA_ERR_BAD_ARG;   // the consumer applies "+ bias" only
+  if (post) {
+    post->fused = h->fused_post && a.bm == 256 && a.ksplit <= 1 && a.Cout == 192 && a.Npad == 192 &&
+                  a.epi == EPI_BIAS && a.out_coff == 0 && a.out_cs == 192 && post->s_out && post->v_out;
+    if (post->fused) {
+      a.post = 1; a.post_w = post->gamma_w; a.post_beta = post->beta; a.post_s = post->s_out; a.post_v = post->v_out;
+      a.flops += 2.0 * a.B * a.Hout * a.Wout * 192.0 * 192.0;
+    }
+  }
   // bf16x3 where it is faster: the IGDN-backward prologue (3 prefetched operands) and the 2-wave
   // BN=96 tile spill to scratch in that mode and measured slower than their f32 instances (193 vs
   // 177 us, 96 vs 88 us), so those launches stay on the f32 MFMA kernel (2.21 -> 2.30 img/s).
@@ -487,14 +503,15 @@ ConvArgs base_args(const PackedConv& pc, int B, int Hg, int Wg) {
 // ---- layer launchers (all: in/out NHWC device) ---------------------------------------------
 // transposed 5x5/2: [B,Hi,Wi,Cin] -> [B,2Hi,2Wi,Cout]
 int deconv_fwd(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int B,
-               int Hi, int Wi, float* out, int epi, hipStream_t st, Deferred* defer = nullptr) {
+               int Hi, int Wi, float* out, int epi, hipStream_t st, Deferred* defer = nullptr,
+               PostGdn* post = nullptr) {
   ConvArgs a = base_args(pc, B, Hi, Wi);
   a.in = in; a.out = out; a.bias = bias;
   a.Hin = Hi; a.Win = Wi; a.Hout = 2 * Hi; a.Wout = 2 * Wi;
   a.s_in = 1; a.s_out = 2; a.epi = epi;
   taps_deconv5_s2(a);
   a.flops = 2.0 * B * Hi * Wi * 25.0 * pc.Kc * pc.N;
-  return conv_launch(h, a, st, defer);
+  return conv_launch(h, a, st, defer, post);
 }
 
 // stride-2 5x5 conv over `in` [B,Hi,Wi,K] -> [B,Ho,Wo,N]; used for analysis forward and for the
@@ -746,13 +763,18 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   const bool fz = h->fused_gdn;
   for (int L = 0; L < 3; ++L) {
     Deferred d;
+    PostGdn pg;
+    pg.gamma_w = h->gs_gdn_f[L].w; pg.beta = h->gs_beta[L]; pg.s_out = h->s[L].p; pg.v_out = h->v[L].p;
     SGACHK(tick());
     h->cur_tag = kFwd[L];
-    SGACHK(deconv_fwd(h, h->gs_f[L], h->gs_bias[L], cur, B, hh, ww, h->u[L].p, EPI_BIAS, st, fz ? &d : nullptr));
+    SGACHK(deconv_fwd(h, h->gs_f[L], h->gs_bias[L], cur, B, hh, ww, h->u[L].p, EPI_BIAS, st, fz ? &d : nullptr,
+                      fz ? &pg : nullptr));
     hh *= 2; ww *= 2;
-    SGACHK(tick());
-    h->cur_tag = kIgdn[L];
-    SGACHK(gdn_fwd(h, h->gs_gdn_f[L], h->gs_beta[L], h->u[L].p, B, hh, ww, h->s[L].p, h->v[L].p, true, st, &d));
+    if (!pg.fused) {           // otherwise the IGDN ran as the post-phase of the convolution launch
+      SGACHK(tick());
+      h->cur_tag = kIgdn[L];
+      SGACHK(gdn_fwd(h, h->gs_gdn_f[L], h->gs_beta[L], h->u[L].p, B, hh, ww, h->s[L].p, h->v[L].p, true, st, &d));
+    }
     cur = h->v[L].p;
   }
   SGACHK(tick());
@@ -1098,6 +1120,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   if (env) h->fork_at = atoi(env);
   env = getenv("SGA_FUSED_GDN");
   h->fused_gdn = !(env && env[0] == '0');
+  env = getenv("SGA_FUSED_POST");
+  h->fused_post = !(env && env[0] == '0');
   env = getenv("SGA_NO_SPLITK");
   h->no_splitk = env && env[0] == '1';
   env = getenv("SGA_PROFILE_BY_LAYER");

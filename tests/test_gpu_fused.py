@@ -1,6 +1,7 @@
 """The fused GDN tile kernel (csrc/gdn_fused.hip: split-K slab sum or 3-channel conv prologue +
 resident-operand C x C contraction + epilogue, one launch) against the launches it replaces
-(conv -> splitk_reduce -> stand-alone GDN kernel; SGA_FUSED_GDN=0): the same f32 fmaf chains in the
+(conv -> splitk_reduce -> stand-alone GDN kernel; SGA_FUSED_GDN=0), and the IGDN post-phase of the big
+transposed convolution (conv_mfma.hip, POST = 1) against a separate IGDN launch: the same f32 fmaf chains in the
 same order, so the two paths must agree BIT FOR BIT -- in the encoder (GDN forward,
 nn_models.py:17-25), in one SGA step (IGDN forward / backward, nn_models.py:51-59) and over a short
 run.  Parity of either path with the oracle is covered by the other GPU test files."""
@@ -35,7 +36,9 @@ def _pair(C, B, H, W):
 # shapes: every tile shape of gdn_fused.hip (general / 32-row "small", C = 64..256), ragged sizes,
 # split and unsplit producers
 SHAPES = [(64, 2, 64, 64), (64, 1, 50, 70), (128, 1, 37, 41), (192, 2, 64, 48), (192, 1, 256, 256),
-          (256, 1, 96, 80), (192, 3, 128, 192), (256, 1, 200, 264)]
+          (256, 1, 96, 80), (192, 3, 128, 192), (256, 1, 200, 264),
+          # >= 1024 tiles in gs2.fwd: the IGDN runs as the post-phase of the convolution launch (conv_mfma.hip POST)
+          (192, 2, 512, 512), (192, 2, 520, 504)]
 
 
 @pytest.mark.parametrize("C,B,H,W", SHAPES)
