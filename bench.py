@@ -199,12 +199,12 @@ def main():
     # FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 on gfx950; scripts/pmc_traffic.py) ------
     if roofline is not None:
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 tr = json.load(f)
             ent = tr.get(roofline["kernel"])
             if ent:
                 roofline["traffic"] = ent["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = tr.get("_source")
+                roofline["traffic_source"] = tr.get("_source") + "; measured at commit " + str(tr.get("_commit"))
         except (OSError, ValueError):
             pass
 

@@ -625,12 +625,8 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
   }
   if (a.bm == 256) wm = 4;
   if (a.bm == 64) tm = 1;
-  if (a.post) {
-    snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,0,false,false,1>", tm, tn, wm, wn);
-    return;
-  }
-  snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%s>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
-           a.smallc ? "true" : "false", (a.x3 && !a.smallc && bn != 32) ? "true" : "false");
+  snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%s,%d>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
+           a.smallc ? "true" : "false", (a.x3 && !a.smallc && bn != 32) ? "true" : "false", a.post ? 1 : 0);
 }
 
 int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream) {

@@ -251,7 +251,7 @@ int sga_op_rate_terms(sga_handle* h, const float* y_tilde, const float* z_tilde,
  * kernel symbol: launches, summed duration, summed ALGORITHMIC flops (useful MACs x 2, no
  * zero-stuffed taps, no channel padding). */
 typedef struct sga_kernel_stat {
-  char name[64];          /* kernel symbol as rocprofv3 prints it, e.g. conv_mfma_kernel<2,3,2,2,0,false> */
+  char name[64];          /* kernel symbol as rocprofv3 prints it, e.g. conv_mfma_kernel<2,3,2,2,0,false,false,0> */
   int64_t launches;
   double ms_total;
   double flops_total;
