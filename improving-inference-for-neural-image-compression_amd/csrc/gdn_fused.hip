@@ -181,26 +181,32 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
     biasv[kc] = (PRO != GDN_PRO_CONV3 && a.bias) ? ld4(a.bias + pc * 4 + kc * CW * 4) : zero4;
   }
   f32x4 e1[NF], e2[MODE == GDN_IGDN_BWD ? NF : 1];
+  // Row groups are software-pipelined: group kr+1's loads are issued before group kr is consumed, so two
+  // groups are in flight (not all four: the backward instance has three input streams and 96 epilogue
+  // registers to keep; a compiler barrier stops hipcc from hoisting every load to the top and spilling).
+  f32x4 t[2][KC], uu[MODE == GDN_IGDN_BWD ? 2 : 1][KC], ss[MODE == GDN_IGDN_BWD ? 2 : 1][KC];
+  auto issue = [&](int kr, int slot) {
+    const int row = pr + R * kr;
+    const size_t ro = tbase + (size_t)(row < rvalid ? row : 0) * C;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      if constexpr (PRO == GDN_PRO_CONV3) t[slot][kc] = *reinterpret_cast<const f32x4*>(tp + kr * R * TP + kc * CW * 4);
+      else t[slot][kc] = ld4(a.src + ro + kc * CW * 4);
+      if constexpr (MODE == GDN_IGDN_BWD) {
+        uu[slot][kc] = ld4(a.u + ro + kc * CW * 4);
+        ss[slot][kc] = ld4(a.s + ro + kc * CW * 4);
+      }
+    }
+  };
+  issue(0, 0);
 #pragma unroll
   for (int kr = 0; kr < KR; ++kr) {
+    const int slot = kr & 1;
     const int row = pr + R * kr;
     const bool ok = row < rvalid;
     const size_t ro = tbase + (size_t)(ok ? row : 0) * C;
-    f32x4 t[KC], uu[MODE == GDN_IGDN_BWD ? KC : 1], ss[MODE == GDN_IGDN_BWD ? KC : 1];
-    if constexpr (PRO == GDN_PRO_CONV3) {
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) t[kc] = *reinterpret_cast<const f32x4*>(tp + kr * R * TP + kc * CW * 4);
-    } else {
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) t[kc] = ld4(a.src + ro + kc * CW * 4);
-    }
-    if constexpr (MODE == GDN_IGDN_BWD) {
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        uu[kc] = ld4(a.u + ro + kc * CW * 4);
-        ss[kc] = ld4(a.s + ro + kc * CW * 4);
-      }
-    }
+    if (kr + 1 < KR) issue(kr + 1, slot ^ 1);
+    if constexpr (MODE == GDN_IGDN_BWD) asm volatile("" ::: "memory");
     if constexpr (PRO != GDN_PRO_CONV3) {
       if (smax > 1) {
         int srow = a.nsplit[0];
@@ -217,28 +223,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
 #pragma unroll
           for (int kc = 0; kc < KC; ++kc) x[kc] = ld4(ps + kc * CW * 4);
 #pragma unroll
-          for (int kc = 0; kc < KC; ++kc) t[kc] = s < srow ? t[kc] + x[kc] : t[kc];
+          for (int kc = 0; kc < KC; ++kc) t[slot][kc] = s < srow ? t[slot][kc] + x[kc] : t[slot][kc];
         }
       }
       if (a.bias) {
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) t[kc] += biasv[kc];
+        for (int kc = 0; kc < KC; ++kc) t[slot][kc] += biasv[kc];
       }
     }
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       f32x4 av;
       if constexpr (MODE == GDN_IGDN_BWD) {
-        av = t[kc] * uu[kc] / ss[kc];            // operand of the contraction: g*u/s
-        e1[kr * KC + kc] = t[kc] * ss[kc];       // g*s
-        e2[kr * KC + kc] = uu[kc];
+        av = t[slot][kc] * uu[slot][kc] / ss[slot][kc];      // operand of the contraction: g*u/s
+        e1[kr * KC + kc] = t[slot][kc] * ss[slot][kc];       // g*s
+        e2[kr * KC + kc] = uu[slot][kc];
       } else {
-        av = t[kc] * t[kc];
-        e1[kr * KC + kc] = t[kc];
+        av = t[slot][kc] * t[slot][kc];
+        e1[kr * KC + kc] = t[slot][kc];
       }
       *reinterpret_cast<f32x4*>(tp + kr * R * TP + kc * CW * 4) = ok ? av : zero4;
     }
-    // keep the next row group's loads out of this one (VGPR budget of the backward instances)
     if constexpr (MODE == GDN_IGDN_BWD) asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }

@@ -107,8 +107,6 @@ struct sga_handle {
   int fork_at = 0;                 // main-chain launch index at which the hyper branch is forked (SGA_FORK_AT)
   int dbg_it = -1;                 // iteration being enqueued (SGA_DEBUG_DUMP)
   hipEvent_t ev_fork_cap = nullptr, ev_join_cap = nullptr;   // while `st` is being captured
-  hipEvent_t ev_fork2 = nullptr, ev_fork2_cap = nullptr;     // second fork point (backward of the hyper branch)
-  int fork2_at = 0;                                            // SGA_FORK2_AT
   bool overlap = true;             // SGA_NO_OVERLAP=1 disables
   ImgSums* sums = nullptr;
   StepCtx* ctx = nullptr;
@@ -709,11 +707,9 @@ int encode_impl(sga_handle* h, const Geom& g, const float* x, float* y, float* z
 // Hyper-prior branch given z_tilde (and y_tilde for the conditional): p(z_tilde), (mu, sigma) =
 // h_s(z_tilde), p(y_tilde | z_tilde) and, with_grad, the data-gradients back to z_tilde
 // (sga.py:100-108, 126-136 and their part of sga.py:164).  Every launch goes to `st`.
-// parts: 1 = forward (prior, h_s, Gaussian conditional), 2 = the data-gradients back to z_tilde, 3 = both
-int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, bool density = false, int parts = 3) {
+int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, bool density = false) {
   const int B = g.B, C = h->C;
   const float il = inv_ln2_hw(g);
-  if (parts & 1) {
   if (density)   // bits-back: prior DENSITY (bb_sga.py:105-106)
     HIPCHK(h, launch_factorized_pdf(h->zt.p, h->eb_packed, h->ctx, B, g.zh * g.zw, C, il, h->sums,
                                     with_grad ? h->g_zt_eb.p : nullptr, nullptr, nullptr, st));
@@ -728,8 +724,7 @@ int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, b
   SGACHK(conv3(h, h->hs_f[2], h->hs_bias[2], h->hs1.p, h->C15, B, g.hsh, g.hsw, h->ms.p, true, EPI_BIAS, nullptr, st));
   HIPCHK(h, launch_gaussian(h->yt.p, h->ms.p, h->ctx, B, g.yh, g.yw, g.hsh, g.hsw, C, il, h->sums,
                             with_grad ? h->g_yt_rate.p : nullptr, with_grad ? h->g_ms.p : nullptr, st));
-  }
-  if (!with_grad || !(parts & 2)) return SGA_OK;
+  if (!with_grad) return SGA_OK;
   h->cur_tag = "hs2.bwd";
   SGACHK(conv3(h, h->hs_b[2], nullptr, h->g_ms.p, 2 * C, B, g.hsh, g.hsw, h->g_hs1.p, false,
                EPI_RELU_MASK, h->hs1.p, st));
@@ -748,18 +743,16 @@ int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, b
 // `side`: called once, right before main-chain launch number `fork_at` (0 = the first one), to
 // enqueue whatever runs concurrently on the second stream.
 int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, hipStream_t st,
-                 int fork_at = 0, int fork2_at = 0, const std::function<int(int)>* side = nullptr) {
+                 int fork_at = 0, const std::function<int()>* side = nullptr) {
   int launches = 0;
-  bool side_started = false, side2_started = false;
+  bool side_started = false;
   auto tick = [&]() -> int {      // call before every main-chain launch
-    if (side && !side_started && launches >= fork_at) { side_started = true; SGACHK((*side)(1)); }
-    if (side && side_started && !side2_started && launches >= fork2_at) { side2_started = true; SGACHK((*side)(2)); }
+    if (side && !side_started && launches >= fork_at) { side_started = true; SGACHK((*side)()); }
     ++launches;
     return SGA_OK;
   };
   auto finish_side = [&]() -> int {
-    if (side && !side_started) { side_started = true; SGACHK((*side)(1)); }
-    if (side && !side2_started) { side2_started = true; SGACHK((*side)(2)); }
+    if (side && !side_started) { side_started = true; SGACHK((*side)()); }
     return SGA_OK;
   };
   const int B = g.B;
@@ -849,22 +842,18 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
   hipEvent_t evf = cs == hipStreamCaptureStatusActive ? h->ev_fork_cap : h->ev_fork;
   hipEvent_t evj = cs == hipStreamCaptureStatusActive ? h->ev_join_cap : h->ev_join;
   bool forked = false;
-  // part 1 = the branch's forward, part 2 = its backward: each starts once the main chain has reached
-  // its own fork point (the backward is best placed beside the small kernels at the END of the main
-  // chain, not beside the big convolutions in the middle)
-  const std::function<int(int)> side = [&](int part) -> int {
-    hipEvent_t ev = part == 1 ? evf : (cs == hipStreamCaptureStatusActive ? h->ev_fork2_cap : h->ev_fork2);
-    HIPCHK(h, hipEventRecord(ev, st));
-    HIPCHK(h, hipStreamWaitEvent(h->sB, ev, 0));
+  const std::function<int()> side = [&]() -> int {
+    HIPCHK(h, hipEventRecord(evf, st));
+    HIPCHK(h, hipStreamWaitEvent(h->sB, evf, 0));
     forked = true;
     h->cur_part = &h->partB;
     const char* tag = h->cur_tag;
-    const int rc = hyper_branch(h, g, with_grad, h->sB, density, part);
+    const int rc = hyper_branch(h, g, with_grad, h->sB, density);
     h->cur_part = &h->part;
     h->cur_tag = tag;
     return rc;
   };
-  const int rc = synth_branch(h, g, x, with_grad, st, h->fork_at, h->fork2_at, &side);
+  const int rc = synth_branch(h, g, x, with_grad, st, h->fork_at, &side);
   // always join, even on error, so a capture in progress is not left forked
   if (forked) {
     const hipError_t e1 = hipEventRecord(evj, h->sB);
@@ -915,8 +904,6 @@ void free_all(sga_handle* h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_fork_cap) (void)hipEventDestroy(h->ev_fork_cap);
-  if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
-  if (h->ev_fork2_cap) (void)hipEventDestroy(h->ev_fork2_cap);
   if (h->ev_join_cap) (void)hipEventDestroy(h->ev_join_cap);
   if (h->sB) (void)hipStreamDestroy(h->sB);
   for (void* p : h->owned) (void)hipFree(p);
@@ -1114,9 +1101,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
         hipEventCreateWithFlags(&h->ev_fork, evflags) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, evflags) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork_cap, evflags) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join_cap, evflags) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork2, evflags) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork2_cap, evflags) != hipSuccess)
+        hipEventCreateWithFlags(&h->ev_join_cap, evflags) != hipSuccess)
       return fail(SGA_ERR_HIP);
   }
   env = getenv("SGA_PRECISION");
@@ -1137,8 +1122,6 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   if (env) h->bm64_max = atoi(env);
   env = getenv("SGA_FORK_AT");
   if (env) h->fork_at = atoi(env);
-  env = getenv("SGA_FORK2_AT");
-  if (env) h->fork2_at = atoi(env);
   env = getenv("SGA_FUSED_GDN");
   h->fused_gdn = !(env && env[0] == '0');
   env = getenv("SGA_FUSED_POST");
