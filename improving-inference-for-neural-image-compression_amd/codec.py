@@ -351,10 +351,18 @@ class SGACodec:
         t = t[:, :yh, :yw, :]
         return t[..., :self.C].contiguous(), torch.exp(t[..., self.C:]).contiguous()
 
-    def _entropy_coder(self, weights=None):
-        if getattr(self, "_ec", None) is None:
+    def _entropy_coder(self, weights=None, device_tables=True):
+        """The coder's quantised CDF tables come from the SAME device kernels that evaluate the entropy
+        models in the SGA step (factorized mass, box-convolved Gaussian), so that what is coded is the
+        model whose rate was optimised; device_tables=False builds them with numpy instead."""
+        if getattr(self, "_ec", None) is None or getattr(self, "_ec_dev", None) != device_tables:
             from .entropy_coding import EntropyCoder
-            self._ec = EntropyCoder(weights if weights is not None else self._weights_for_ec)
+            dm = None
+            if device_tables:
+                dm = (lambda v: self.factorized_likelihood(v)[0].cpu().numpy(),
+                      lambda y, mu, sr: self.gaussian_likelihood(y, mu, sr)[0].cpu().numpy())
+            self._ec = EntropyCoder(weights if weights is not None else self._weights_for_ec, device_models=dm)
+            self._ec_dev = device_tables
         return self._ec
 
     def compress_latents(self, x_shape, y_hat, z_hat) -> bytes:

@@ -109,13 +109,22 @@ def quantise_pmf(pmf: np.ndarray) -> np.ndarray:
 
 
 class EntropyCoder:
-    def __init__(self, weights: dict, z_max_abs: int = 96, tail: float = 2.0 ** -14):
+    def __init__(self, weights: dict, z_max_abs: int = 96, tail: float = 2.0 ** -14, device_models=None):
+        """device_models: optional pair (mass_fn, box_fn) evaluating the two entropy models with the
+        HIP kernels of the SGA step instead of numpy -- `mass_fn(v [K, C]) -> p [K, C]` (factorized
+        mass, sga_op_factorized_likelihood) and `box_fn(y, mu, sigma_raw) -> p` (box-convolved
+        Gaussian, sga_op_gaussian_likelihood); see SGACodec._entropy_coder(device_tables=True).
+        Encoder and decoder must build their tables the same way."""
         self.C = weights["eb.m0"].shape[0]
         self.scale_table = np.exp(np.linspace(math.log(SCALES_MIN), math.log(SCALES_MAX), SCALES_LEVELS))
         tables, lens, offs = [], [], []
         # ---- z: one table per channel -------------------------------------------------------
         ks = np.arange(-z_max_abs, z_max_abs + 1, dtype=np.float64)
-        mass = factorized_mass(weights, ks)                    # [K, C]
+        if device_models is not None:
+            grid = np.broadcast_to(ks[:, None], (ks.size, self.C)).astype(np.float32)
+            mass = np.asarray(device_models[0](grid), np.float64)
+        else:
+            mass = factorized_mass(weights, ks)                # [K, C]
         for c in range(self.C):
             m = mass[:, c]
             keep = np.nonzero(m >= tail / 8)[0]
@@ -126,15 +135,28 @@ class EntropyCoder:
         self.z_tab0 = 0
         # ---- y: scale level x mean-fraction bin -----------------------------------------------
         self.y_tab0 = len(tables)
+        specs = []                                               # (R, f, s) of every y table, in table order
         for s in self.scale_table:
             R = int(math.ceil(6.0 * s + 1.0))                    # +-6 sigma, rest escapes
-            r = np.arange(-R, R + 1, dtype=np.float64)
             for j in range(MEAN_BINS):
-                f = (j + 0.5) / MEAN_BINS - 0.5
+                specs.append((R, (j + 0.5) / MEAN_BINS - 0.5, s))
+        dev = None
+        if device_models is not None:                            # all tables' grids in ONE device call
+            ys = np.concatenate([np.arange(-R, R + 1, dtype=np.float32) for R, _, _ in specs])
+            mus = np.concatenate([np.full(2 * R + 1, f, np.float32) for R, f, _ in specs])
+            srs = np.concatenate([np.full(2 * R + 1, math.log(s), np.float32) for R, _, s in specs])
+            dev = np.asarray(device_models[1](ys, mus, srs), np.float64)
+        pos = 0
+        for R, f, s in specs:
+            r = np.arange(-R, R + 1, dtype=np.float64)
+            if dev is not None:
+                pm = dev[pos:pos + r.size]
+                pos += r.size
+            else:
                 pm = _phi((r + 0.5 - f) / s) - _phi((r - 0.5 - f) / s)
-                tables.append(quantise_pmf(pm))
-                lens.append(r.size + 1)
-                offs.append(-R)
+            tables.append(quantise_pmf(pm))
+            lens.append(r.size + 1)
+            offs.append(-R)
         self.stride = max(t.size for t in tables)
         self.cdf = np.zeros((len(tables), self.stride), np.uint32)
         for i, t in enumerate(tables):

@@ -18,6 +18,18 @@ of *effective* tensors `weights.layer_shapes()` describes (SURVEY.md 8(a) a4, a5
                                      gamma = max(r, 2^-18)^2 - 2^-36
   factorized prior                 : softplus(matrix_k), bias_k, tanh(factor_k)
 
+Variable names expected in the checkpoint (Keras layer names of nn_models.py under tfc 1.3; matched by
+regular expression on scope + suffix, optimizer slots `/Adam*` and moving averages ignored):
+
+  analysis_transform/layer_{0..3}/kernel_rdft, .../bias          layer_{0..2}/gdn_{0..2}/reparam_beta|reparam_gamma
+  synthesis_transform/layer_{0..3}/kernel_rdft, .../bias         layer_{0..2}/igdn_{0..2}/reparam_beta|reparam_gamma
+  hyper_analysis_transform/layer_{0..2}/kernel_rdft, layer_{0,1}/bias            (layer_2: use_bias=False, nn_models.py:95)
+  mbt2018_hyper_synthesis_transform/layer_{0..2}/kernel, .../bias                (kernel_parameterizer=None)
+  entropy_bottleneck/matrix_{0..3}, bias_{0..3}, factor_{0..2}, quantiles        (the scope the dummy call at
+      sga.py:100 / danneal.py:102-111 exists to create: without it the variables would be named "matrix_0", ... and
+      `Saver.restore` fails with "Key bias_0 not found in checkpoint"); the bits-back models keep the same
+      tensors under the scope of learned_prior.BMSHJ2018Prior (no `quantiles`)
+
 STATUS: the container format code is exercised by tests/test_host.py against a minimal writer
 (uncompressed and snappy-compressed blocks).  The variable naming and the RDFT basis follow
 tfc 1.3 as published; they are UNVERIFIED here -- no real checkpoint exists offline and TF/tfc

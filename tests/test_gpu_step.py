@@ -413,3 +413,35 @@ def test_bitstream_round_trip(gpu_out_dir):
     x_hat = codec.reconstruct(y2, H, W)
     mse = ((x_hat * 255).round() - torch.as_tensor(x).cuda() * 255).pow(2).mean(dim=(1, 2, 3)).cpu().numpy()
     assert np.allclose(mse, m["mse"], rtol=1e-3)
+
+
+def test_device_built_cdf_tables(gpu_out_dir):
+    """the coder's quantised CDF tables are built from the device entropy-model kernels
+    (sga_op_factorized_likelihood / sga_op_gaussian_likelihood -- the models whose rate the SGA loop
+    optimises).  Against the tables built from the float64 numpy restatement: valid CDFs, frequencies
+    within 2 counts of 65536 everywhere (float32 masses + the total fix-up), the same ideal code length
+    to 1e-4, and an exact encode/decode round trip."""
+    from sga_amd import entropy_coding as ec
+    C, B, H, W = 64, 2, 64, 64
+    codec, orc, _ = setup(C, B, H, W)
+    dev = codec._entropy_coder(device_tables=True)
+    ref = ec.EntropyCoder(codec._weights_for_ec)
+    assert dev.cdf.shape == ref.cdf.shape and np.array_equal(dev.lens, ref.lens) and np.array_equal(dev.offs, ref.offs)
+    worst = 0
+    for t in range(dev.cdf.shape[0]):
+        n = dev.lens[t] + 1
+        cd, cr = dev.cdf[t, :n].astype(np.int64), ref.cdf[t, :n].astype(np.int64)
+        assert cd[0] == 0 and cd[-1] == ec.TOTAL and (np.diff(cd) >= 1).all()
+        worst = max(worst, int(np.abs(np.diff(cd) - np.diff(cr)).max()))
+    assert worst <= 2, worst
+    rng = np.random.RandomState(5)
+    shape = (2, 4, 4, C)
+    mu = (rng.standard_normal(shape) * 2).astype(np.float32)
+    sigma = np.exp(rng.standard_normal(shape)).astype(np.float32)
+    y = np.rint(mu + sigma * rng.standard_normal(shape)).astype(np.float32)
+    z = np.rint(rng.standard_normal((2, 1, 1, C)) * 4).astype(np.float32)
+    assert np.array_equal(dev.decode_y(dev.encode_y(y, mu, sigma), mu, sigma), y)
+    assert np.array_equal(dev.decode_z(dev.encode_z(z), z.shape), z)
+    a, b = dev.ideal_bits_y(y, mu, sigma), ref.ideal_bits_y(y, mu, sigma)
+    report(gpu_out_dir, "device_cdf_tables", worst_freq_diff=worst, ideal_bits_dev=a, ideal_bits_ref=b)
+    assert abs(a / b - 1) < 1e-4

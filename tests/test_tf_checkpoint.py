@@ -174,3 +174,38 @@ def test_medians_come_from_quantiles():
     assert np.array_equal(got["eb.medians"], w["eb.medians"])
     del t["entropy_bottleneck/quantiles"]            # e.g. the bits-back prior: no medians, no error
     assert "eb.medians" not in tfc.effective_weights_from_tensors(t, C)
+
+
+@pytest.mark.parametrize("shape", [(5, 5), (3, 3), (4, 6)])
+def test_irdft_matrix_columns_are_separable_real_fourier_modes(shape):
+    """`kernel = irdft_matrix(support) @ kernel_rdft` (tfc RDFTParameterizer): the basis must be the
+    orthonormal, separable REAL DFT basis of the kernel support (the rfft is applied axis by axis with
+    real and imaginary parts kept as separate real coefficients).  Checked against numpy's FFT: every
+    column, reshaped to the support, has its whole 2-D spectrum on ONE |frequency| pair (+-u, +-v)
+    (np.fft.fftn); every such class is covered exactly as often as it has real degrees of freedom;
+    column 0 is the constant (DC) mode; analysis is the transpose."""
+    kh, kw = shape
+    M = tfc.irdft_matrix(shape).astype(np.float64)              # [kh*kw (space), kh*kw (coefficients)]
+    assert np.allclose(M @ M.T, np.eye(kh * kw), atol=1e-6)
+    assert np.allclose(M[:, 0], 1.0 / np.sqrt(kh * kw), atol=1e-6)
+    seen = {}
+    for k in range(kh * kw):
+        p = np.abs(np.fft.fftn(M[:, k].reshape(kh, kw), norm="ortho")) ** 2
+        assert abs(p.sum() - 1.0) < 1e-5                          # unit energy
+        (u, v) = np.unravel_index(np.argmax(p), p.shape)
+        cls = {((su * u) % kh, (sv * v) % kw) for su in (1, -1) for sv in (1, -1)}
+        assert sum(p[a] for a in cls) > 1 - 1e-5, (k, p.round(3))
+        key = (min(u, (-u) % kh), min(v, (-v) % kw))
+        seen[key] = seen.get(key, 0) + 1
+    dof = lambda f, n: 1 if (f == 0 or 2 * f == n) else 2        # a self-conjugate 1-D frequency is real
+    for (u, v), n in seen.items():
+        assert n == dof(u, kh) * dof(v, kw), (u, v, n)
+    assert sum(seen.values()) == kh * kw
+    rng = np.random.RandomState(0)
+    c = rng.standard_normal(kh * kw)
+    x = M @ c
+    assert np.allclose(M.T @ x, c, atol=1e-5)                     # analysis = transpose (orthonormal)
+    # a pure DC coefficient synthesises the constant kernel, as np.fft.irfftn of a DC-only spectrum does
+    spec = np.zeros((kh, kw // 2 + 1), complex)
+    spec[0, 0] = np.sqrt(kh * kw)
+    assert np.allclose(M[:, 0].reshape(kh, kw), np.fft.irfftn(spec, s=shape), atol=1e-6)
