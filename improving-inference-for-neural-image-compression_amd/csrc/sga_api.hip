@@ -221,6 +221,11 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     a.tiles_per_phase = cdiv(a.B * a.Hg * a.Wg, 64);
   }
   a.ksplit = pick_ksplit(h, a);
+  {
+    const long long blocks = (long long)a.nphase * a.tiles_per_phase * a.ntiles_n;
+    const int per_cu = a.bm == 64 ? 3 : (a.bm == 128 ? 2 : 1);
+    a.pair_phases = (a.nphase == 4 && a.ksplit <= 1 && blocks > 256 && blocks <= 256LL * per_cu) ? 1 : 0;
+  }
   if (defer && a.epi != EPI_BIAS) return SGA_ERR_BAD_ARG;   // the consumer applies "+ bias" only
   if (post) {
     post->fused = h->fused_post && a.bm == 256 && a.ksplit <= 1 && a.Cout == 192 && a.Npad == 192 &&
