@@ -1,9 +1,11 @@
 // C -> 3 transposed 5x5/2 convolution (last synthesis layer, nn_models.py:60-63) as a halo-tiled
 // implicit GEMM.  In the generic gather-GEMM each of the 9 (dy,dx) taps re-reads its 128-pixel A
 // tile from global memory (876 MB per launch at B=8, 256^2: HBM-bound, PMC profile r01).  Here a
-// workgroup owns an 8 x 16 tile of input positions, stages the (8+2) x (16+2) halo of one
+// workgroup owns a 4 x 16 tile of input positions, stages the (4+2) x (16+2) halo of one
 // 32-channel chunk in LDS once, and all 9 taps read their A fragments from it at shifted
-// positions: 6.4x less A traffic.  N = 4 phases x 3 channels = 12 columns, padded to 16 and
+// positions.  4 x 16 (not 8 x 16): 40 KB of LDS -> 4 workgroups per CU, and at the bench shape
+// 2048 workgroups = exactly two full rounds of the chip (8 x 16: 1024 workgroups on 768 slots,
+// a third of the chip idle in the second round; 80 -> 72 us).  N = 4 phases x 3 channels = 12 columns, padded to 16 and
 // multiplied with v_mfma_f32_16x16x4_f32 (the 32-wide MFMA would waste 62 % of the tile).
 #include "sga_common.h"
 
@@ -11,15 +13,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int TH = 8, TW = 16;            // input positions per workgroup
+constexpr int TH = 4, TW = 16;            // input positions per workgroup (4 waves x RPW rows x 16)
+constexpr int RPW = TH / 4;               // tile rows per wave
 constexpr int HH = TH + 2, HW = TW + 2;   // halo
-constexpr int NPX = HH * HW;              // 180 halo pixels
-constexpr int PIT = 36;                   // LDS row pitch (32 + 4 floats)
+constexpr int NPX = HH * HW;              // 108 halo pixels
+constexpr int PIT = 40;                   // LDS row pitch (32 + 8 floats): with the 16x16x4 fragment pattern (16 pixels x 4 k-slots per
+                                          // b128 lane group) 36 gives 40 % bank conflicts (PMC), 40 none (slot = 10*pixel + kslot mod 16)
 constexpr int NB = 9 * 16;                // weight rows per chunk: 9 taps x 16 columns
 constexpr int HALO_F4 = NPX * 8;          // float4 per halo chunk
 constexpr int B_F4 = NB * 8;
-constexpr int PH = (HALO_F4 + 255) / 256; // 6
-constexpr int PBW = (B_F4 + 255) / 256;   // 5
+constexpr int PH = (HALO_F4 + 255) / 256;
+constexpr int PBW = (B_F4 + 255) / 256;
 
 __global__ __launch_bounds__(256) void deconv3_halo_kernel(
     const float* __restrict__ in, const float* __restrict__ w /*[C/32][9][16][32]*/,
@@ -60,9 +64,9 @@ __global__ __launch_bounds__(256) void deconv3_halo_kernel(
     }
   };
 
-  f32x4 acc[2];
-  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-  acc[1] = acc[0];
+  f32x4 acc[RPW];
+#pragma unroll
+  for (int s = 0; s < RPW; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int li = lane & 15, g = lane >> 4;
   gload(0);
   for (int c = 0; c < nchunk; ++c) {
@@ -84,16 +88,16 @@ __global__ __launch_bounds__(256) void deconv3_halo_kernel(
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const f32x4 bf = *reinterpret_cast<const f32x4*>(&Bs[(t * 16 + li) * PIT + q * 16 + g * 4]);
-        f32x4 af[2];
+        f32x4 af[RPW];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int hy = 2 * wid + s + dy + 1, hx = li + dx + 1;
+        for (int s = 0; s < RPW; ++s) {
+          const int hy = RPW * wid + s + dy + 1, hx = li + dx + 1;
           af[s] = *reinterpret_cast<const f32x4*>(&Hs[(hy * HW + hx) * PIT + q * 16 + g * 4]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
+          for (int s = 0; s < RPW; ++s)
             acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][r], bf[r], acc[s], 0, 0, 0);
       }
     }
@@ -105,8 +109,8 @@ __global__ __launch_bounds__(256) void deconv3_halo_kernel(
     const int pp = n / 3, ch = n - pp * 3;
     const float bv = bias ? bias[ch] : 0.f;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int iy = ty0 + 2 * wid + s;
+    for (int s = 0; s < RPW; ++s) {
+      const int iy = ty0 + RPW * wid + s;
       if (iy >= Hi) continue;
       const int oy = 2 * iy + (pp >> 1);
       if (oy >= Ho) continue;
