@@ -1,0 +1,26 @@
+"""GPU box: us per SGA iteration (bench shape, graph replay) under different environment knobs.
+usage: python scripts/env_sweep.py "" "SGA_GRAPH_UNROLL=4" "SGA_GRAPH_UNROLL=8,SGA_SIDE_LAST=1" ..."""
+import os, sys, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+code = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+import torch, sga_amd
+from sga_amd.codec import SGACodec
+c = SGACodec(sga_amd.make_synthetic_weights(192, 0), 192, 8, 256, 256)
+x = torch.rand(8, 256, 256, 3, generator=torch.Generator().manual_seed(1000)).cuda()
+y, z = c.encode(x)
+c.run(x, 0.01, its=40, metrics=False); torch.cuda.synchronize()
+best = 1e9
+for _ in range(4):
+    t = time.time(); r = c.run(x, 0.01, its=400, seed=7, metrics=False); torch.cuda.synchronize()
+    best = min(best, (time.time() - t) / 400)
+print("%%.1f %%s" %% (best * 1e6, float(r[0].double().sum())))
+''' % ROOT
+for cfg in sys.argv[1:] or [""]:
+    env = dict(os.environ)
+    for kv in filter(None, cfg.split(",")):
+        k, v = kv.split("=")
+        env[k] = v
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    print("%-48s us/it, checksum:" % (cfg or "(default)"), out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-400:], flush=True)

@@ -6,7 +6,7 @@ def short(n):
     n = re.sub(r'\(anonymous namespace\)::', '', n); n = re.sub(r'\(.*$', '', n); n = n.replace('void ', '')
     return n[:58]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'advance_ctx' in r['Kernel_Name'] or 'k_finalize_step' in r['Kernel_Name'] and False]
+idx = [i for i, r in enumerate(rows) if 'k_sample_yz' in r['Kernel_Name']]      # first launch of an iteration
 its = [(int(rows[idx[k + 1]]['Start_Timestamp']) - int(rows[idx[k]]['Start_Timestamp'])) / 1e3 for k in range(10, len(idx) - 2)]
 print("iterations", len(idx), "mean us/it", sum(its) / len(its), "min", min(its))
 i0, i1 = idx[which], idx[which + 1]
