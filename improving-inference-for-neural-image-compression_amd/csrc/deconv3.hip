@@ -8,6 +8,7 @@
 // a third of the chip idle in the second round; 80 -> 72 us).  N = 4 phases x 3 channels = 12 columns, padded to 16 and
 // multiplied with v_mfma_f32_16x16x4_f32 (the 32-wide MFMA would waste 62 % of the tile).
 #include "sga_common.h"
+#include "kernels.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -25,10 +26,19 @@ constexpr int B_F4 = NB * 8;
 constexpr int PH = (HALO_F4 + 255) / 256;
 constexpr int PBW = (B_F4 + 255) / 256;
 
+// MSE = true: the distortion kernel (elementwise.hip k_mse; sga.py:150, 170-173 and the gradient of :161
+// w.r.t. x_tilde) runs in the epilogue on the values still in registers: per-image f64 sums of
+// (x - x_tilde)^2 and (255 x - round(255 clip(x_tilde)))^2, and the zero-bordered gradient image
+// gpad = coef * (x_tilde - x) that igdn2.bwd's 3-channel prologue reads.  Same expressions as k_mse.
+struct Deconv3Mse {
+  const float* x; const StepCtx* ctx; ImgSums* sums; float* gpad; int Hp, Wp;
+};
+
+template <bool MSE>
 __global__ __launch_bounds__(256) void deconv3_halo_kernel(
     const float* __restrict__ in, const float* __restrict__ w /*[C/32][9][16][32]*/,
     const float* __restrict__ bias, float* __restrict__ out, int B, int Hi, int Wi, int C, int Ho,
-    int Wo, int tiles_x, int tiles_y) {
+    int Wo, int tiles_x, int tiles_y, Deconv3Mse ms) {
   __shared__ __attribute__((aligned(16))) float Hs[NPX * PIT];
   __shared__ __attribute__((aligned(16))) float Bs[NB * PIT];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -105,6 +115,12 @@ __global__ __launch_bounds__(256) void deconv3_halo_kernel(
   }
   // D layout of 16x16x4: column (n) = lane & 15, row (position within the 16-wide tile row) = 4*(lane>>4) + reg
   const int n = li;
+  float a0 = 0.f, a1 = 0.f;
+  float coef = 0.f;
+  if constexpr (MSE) {
+    if (ms.ctx->lambda > 0.f)
+      coef = ms.ctx->lambda * 2.0f * 65025.0f * ms.ctx->loss_scale / (float)(Ho * Wo * 3);
+  }
   if (n < 12) {
     const int pp = n / 3, ch = n - pp * 3;
     const float bv = bias ? bias[ch] : 0.f;
@@ -118,8 +134,37 @@ __global__ __launch_bounds__(256) void deconv3_halo_kernel(
       for (int reg = 0; reg < 4; ++reg) {
         const int ix = tx0 + 4 * g + reg;
         const int ox = 2 * ix + (pp & 1);
-        if (ix < Wi && ox < Wo) out[((size_t)(b * Ho + oy) * Wo + ox) * 3 + ch] = acc[s][reg] + bv;
+        if (ix < Wi && ox < Wo) {
+          const size_t idx = ((size_t)(b * Ho + oy) * Wo + ox) * 3 + ch;
+          const float tv = acc[s][reg] + bv;
+          out[idx] = tv;
+          if constexpr (MSE) {
+            const float xv = ms.x[idx];
+            const float d = xv - tv;
+            a0 += d * d;
+            const float q = rintf(fminf(fmaxf(tv, 0.f), 1.f) * 255.0f);
+            const float dq = xv * 255.0f - q;
+            a1 += dq * dq;
+            ms.gpad[((size_t)(b * ms.Hp + oy + 2) * ms.Wp + ox + 2) * 3 + ch] = coef * (tv - xv);
+          }
+        }
       }
+    }
+  }
+  if constexpr (MSE) {
+    // f32 partials of <= 4 values per lane, f64 across the workgroup, one atomic pair per workgroup
+    double d0 = (double)a0, d1 = (double)a1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      d0 += __shfl_down(d0, o, 64);
+      d1 += __shfl_down(d1, o, 64);
+    }
+    double* red = reinterpret_cast<double*>(Hs);     // the K loop ended with a barrier: Hs is free
+    if (lane == 0) { red[wid] = d0; red[4 + wid] = d1; }
+    __syncthreads();
+    if (tid == 0) {
+      atomicAdd(&ms.sums[b].sq, red[0] + red[1] + red[2] + red[3]);
+      atomicAdd(&ms.sums[b].sq_q, red[4] + red[5] + red[6] + red[7]);
     }
   }
 }
@@ -129,7 +174,16 @@ __global__ __launch_bounds__(256) void deconv3_halo_kernel(
 int launch_deconv3_halo(const float* in, const float* w, const float* bias, float* out, int B,
                         int Hi, int Wi, int C, int Ho, int Wo, hipStream_t stream) {
   const int tiles_x = (Wi + TW - 1) / TW, tiles_y = (Hi + TH - 1) / TH;
-  hipLaunchKernelGGL(deconv3_halo_kernel, dim3(B * tiles_x * tiles_y), dim3(256), 0, stream, in, w,
-                     bias, out, B, Hi, Wi, C, Ho, Wo, tiles_x, tiles_y);
+  hipLaunchKernelGGL(deconv3_halo_kernel<false>, dim3(B * tiles_x * tiles_y), dim3(256), 0, stream, in, w,
+                     bias, out, B, Hi, Wi, C, Ho, Wo, tiles_x, tiles_y, Deconv3Mse{});
+  return (int)hipGetLastError();
+}
+
+int launch_deconv3_halo_mse(const float* in, const float* w, const float* bias, float* out, int B,
+                            int Hi, int Wi, int C, int Ho, int Wo, const float* x, const StepCtx* ctx,
+                            ImgSums* sums, float* gpad, int Hp, int Wp, hipStream_t stream) {
+  const int tiles_x = (Wi + TW - 1) / TW, tiles_y = (Hi + TH - 1) / TH;
+  hipLaunchKernelGGL(deconv3_halo_kernel<true>, dim3(B * tiles_x * tiles_y), dim3(256), 0, stream, in, w,
+                     bias, out, B, Hi, Wi, C, Ho, Wo, tiles_x, tiles_y, Deconv3Mse{x, ctx, sums, gpad, Hp, Wp});
   return (int)hipGetLastError();
 }

@@ -40,6 +40,10 @@ int launch_gaussian_op(const float* y, const float* mu, const float* sraw, int64
 
 // distortion: sums + gradient image g = lambda*2*255^2*loss_scale/(HW3) * (xt - x) written into
 // the zero-bordered buffer gpad [B,Hp,Wp,3] at offset (2,2)  (sga.py:150-161)
+// the C -> 3 transposed convolution with k_mse in its epilogue (deconv3.hip; step only: ctx != null, gpad != null)
+int launch_deconv3_halo_mse(const float* in, const float* w, const float* bias, float* out, int B,
+                            int Hi, int Wi, int C, int Ho, int Wo, const float* x, const StepCtx* ctx,
+                            ImgSums* sums, float* gpad, int Hp, int Wp, hipStream_t stream);
 int launch_mse(const float* x, const float* xt, const StepCtx* ctx, int B, int H, int W, int Hp,
                int Wp, ImgSums* sums, float* gpad, float* xq_out, hipStream_t s);
 

@@ -100,6 +100,7 @@ struct sga_handle {
   int run_B = 0, run_H = 0, run_W = 0, run_its = -1, run_it = 0;   // sga_run_begin/steps state
   float run_lambda = 0.f, run_loss_scale = 1.f; uint64_t run_seed = 0;
   bool split256 = true;            // split-K also for a single-phase launch of exactly 256 tiles (SGA_SPLIT256=0: off)
+  bool fused_mse = true;           // distortion sums + gradient image in gs3.fwd's epilogue (SGA_FUSED_MSE=0: separate k_mse)
   bool fused_post = true;          // IGDN as the post-phase of the producing convolution launch (SGA_FUSED_POST=0: off)
   bool fused_gdn = true;           // gdn_fused.hip instead of the stand-alone GDN launches (SGA_FUSED_GDN=0: off)
   int bm64_max = 256;              // 64-row tiles when the 128-row grid has at most this many blocks (SGA_BM64_MAX; 0 = off)
@@ -630,8 +631,11 @@ int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float*
 }
 
 // C->3 transposed conv (combined phases): [B,Hi,Wi,C] -> out [B,Ho,Wo,3] cropped to (Ho,Wo)
+// `mse_x` != null: the distortion kernel runs in the epilogue (sums, gpad; *mse_done = true) when the halo
+// kernel is in use; otherwise the caller launches k_mse
 int deconv_to3(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int B,
-               int Hi, int Wi, int Ho, int Wo, float* out, hipStream_t st) {
+               int Hi, int Wi, int Ho, int Wo, float* out, hipStream_t st, const float* mse_x = nullptr,
+               int Hp = 0, int Wp = 0, bool* mse_done = nullptr) {
   if (!h->gs3_generic) {
     sga_handle::ProfRec r;
     if (h->profiling) {
@@ -641,7 +645,13 @@ int deconv_to3(sga_handle* h, const PackedConv& pc, const float* bias, const flo
       HIPCHK(h, hipEventCreate(&r.b));
       HIPCHK(h, hipEventRecord(r.a, st));
     }
-    HIPCHK(h, launch_deconv3_halo(in, h->gs3_halo_w, bias, out, B, Hi, Wi, pc.Kc, Ho, Wo, st));
+    if (mse_x && h->fused_mse) {
+      HIPCHK(h, launch_deconv3_halo_mse(in, h->gs3_halo_w, bias, out, B, Hi, Wi, pc.Kc, Ho, Wo, mse_x, h->ctx,
+                                        h->sums, h->gpad.p, Hp, Wp, st));
+      *mse_done = true;
+    } else {
+      HIPCHK(h, launch_deconv3_halo(in, h->gs3_halo_w, bias, out, B, Hi, Wi, pc.Kc, Ho, Wo, st));
+    }
     if (h->profiling) {
       HIPCHK(h, hipEventRecord(r.b, st));
       h->prof.push_back(r);
@@ -789,10 +799,14 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   }
   SGACHK(tick());
   h->cur_tag = "gs3.fwd";
-  SGACHK(deconv_to3(h, h->gs_f[3], h->gs_bias[3], cur, B, hh, ww, g.H, g.W, h->xt.p, st));
-  SGACHK(tick());
-  HIPCHK(h, launch_mse(x, h->xt.p, with_grad ? h->ctx : nullptr, B, g.H, g.W, g.Hp, g.Wp, h->sums,
-                       with_grad ? h->gpad.p : nullptr, with_grad ? nullptr : h->xq.p, st));
+  bool mse_done = false;     // step: the distortion sums and the gradient image come out of gs3.fwd's epilogue
+  SGACHK(deconv_to3(h, h->gs_f[3], h->gs_bias[3], cur, B, hh, ww, g.H, g.W, h->xt.p, st, with_grad ? x : nullptr,
+                    g.Hp, g.Wp, &mse_done));
+  if (!mse_done) {
+    SGACHK(tick());
+    HIPCHK(h, launch_mse(x, h->xt.p, with_grad ? h->ctx : nullptr, B, g.H, g.W, g.Hp, g.Wp, h->sums,
+                         with_grad ? h->gpad.p : nullptr, with_grad ? nullptr : h->xq.p, st));
+  }
   if (!with_grad) {
     SGACHK(finish_side());
     return SGA_OK;
@@ -1150,6 +1164,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->fused_gdn = !(env && env[0] == '0');
   env = getenv("SGA_FUSED_POST");
   h->fused_post = !(env && env[0] == '0');
+  env = getenv("SGA_FUSED_MSE");
+  h->fused_mse = !(env && env[0] == '0');
   env = getenv("SGA_NO_SPLITK");
   h->no_splitk = env && env[0] == '1';
   env = getenv("SGA_PROFILE_BY_LAYER");

@@ -1,5 +1,5 @@
 """GPU box: us per SGA iteration (bench shape, graph replay) under different environment knobs.
-usage: python scripts/env_sweep.py "" "SGA_GRAPH_UNROLL=4" "SGA_GRAPH_UNROLL=8,SGA_SIDE_LAST=1" ..."""
+usage: python scripts/env_sweep.py "" "SGA_GRAPH_UNROLL=4" "A=1;B=2" ..."""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''
@@ -19,7 +19,7 @@ print("%%.1f %%s" %% (best * 1e6, float(r[0].double().sum())))
 ''' % ROOT
 for cfg in sys.argv[1:] or [""]:
     env = dict(os.environ)
-    for kv in filter(None, cfg.split(",")):
+    for kv in filter(None, cfg.split(";")):
         k, v = kv.split("=")
         env[k] = v
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)

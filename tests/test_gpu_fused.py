@@ -59,3 +59,40 @@ def test_fused_equals_unfused_bitwise(C, B, H, W):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert torch.equal(a[2][:, [0, 1, 4, 5, 6]], b[2][:, [0, 1, 4, 5, 6]])
     fused.close(); legacy.close()
+
+
+def _codec_env(name, value, *args):
+    from sga_amd.codec import SGACodec
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return SGACodec(*args)
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+
+
+@pytest.mark.parametrize("C,B,H,W", [(64, 2, 64, 64), (64, 1, 50, 70), (128, 3, 37, 41), (192, 2, 256, 256)])
+def test_distortion_in_the_gs3_epilogue_equals_the_separate_kernel(C, B, H, W):
+    """sga.py:150,161,170-173: squared-error sums and d loss / d x_tilde computed in the epilogue of the C -> 3
+    transposed convolution (deconv3.hip, MSE = true) vs the stand-alone k_mse launch (SGA_FUSED_MSE=0).  The
+    gradient image is the same expression on the same values: gradients BIT-equal; the sums are f32 partials
+    over different groupings accumulated in f64: equal to f32 rounding."""
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    fused = _codec_env("SGA_FUSED_MSE", "1", w, C, B, H, W)
+    plain = _codec_env("SGA_FUSED_MSE", "0", w, C, B, H, W)
+    x = np.random.RandomState(C + W).rand(B, H, W, 3).astype(np.float32)
+    y, z = fused.encode(x)
+    ra = fused.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    rb = plain.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    assert torch.equal(ra["gy"], rb["gy"]) and torch.equal(ra["gz"], rb["gz"])
+    assert float(ra["gy"].abs().max()) > 0
+    assert ra["train_mse"] == pytest.approx(rb["train_mse"], rel=2e-7)
+    assert ra["rd_loss"] == pytest.approx(rb["rd_loss"], rel=2e-7)
+    a = fused.run(x, 0.01, its=20, seed=1)
+    b = plain.run(x, 0.01, its=20, seed=1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.allclose(a[2][:, :4], b[2][:, :4], rtol=1e-6, atol=0, equal_nan=True)
+    fused.close(); plain.close()
