@@ -165,7 +165,38 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
 
+  // Per-tap gather state of the generic path: element offset of this thread's 16-byte piece in each of
+  // its PA rows (channel chunk 0) and whether the tap lands inside the image; the weight rows likewise.
+  // Recomputed when the K walk moves to the next tap (every Cin/32 steps); inside a tap a K-step only
+  // adds ci0 (the index arithmetic was ~50 64-bit VALU instructions per K-step before).
+  long long a_off[PA];
+  bool a_ok[PA];
+  long long b_off = 0;
+  auto set_tap = [&](int tapi) {
+    const ConvTap tp = a.taps[ph.tap_begin + tapi];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int iy = a_iy[p] + tp.dy, ix = a_ix[p] + tp.dx;
+      a_ok[p] = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+      a_off[p] = (long long)((size_t)(a_base[p] + iy * a.Win + ix) * a.in_cs + a.in_coff + chunk * 4);
+    }
+    b_off = (long long)(((size_t)tp.slab * a.Npad + n0 + lrow) * a.Cin + chunk * 4);
+  };
   auto gload = [&](int tapi, int ci0) {
+    if constexpr (!SMALLC && !X3) {
+#pragma unroll
+      for (int p = 0; p < PA; ++p) {
+        const size_t off = (size_t)(a_off[p] + ci0);
+        ra[p] = a_ok[p] ? ld4(a.in + off) : zero4;
+        if constexpr (PRO == PRO_IGDN_BWD) {
+          ra1[p] = a_ok[p] ? ld4(a.aux1 + off) : one4;
+          ra2[p] = a_ok[p] ? ld4(a.aux2 + off) : zero4;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < PB; ++p) rb[p] = ld4(a.w + (size_t)(b_off + ci0) + (size_t)p * RPP * a.Cin);
+      return;
+    }
     const ConvTap tp = a.taps[ph.tap_begin + tapi];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
@@ -230,7 +261,10 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
     k_end = (int)((long long)(split + 1) * nsteps_all / nsplit);
   }
   int tapi = k_begin / nchunk, ci0 = (k_begin - tapi * nchunk) * BK;
-  if (k_begin < k_end) gload(tapi, ci0);
+  if (k_begin < k_end) {
+    if constexpr (!SMALLC && !X3) set_tap(tapi);
+    gload(tapi, ci0);
+  }
 
   const int arow = (wm * TM) * 32 + (lane & 31);
   const int brow = (wn * TN) * 32 + (lane & 31);
@@ -273,8 +307,13 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
 
     // ---- prefetch the next K-step while this one is multiplied ------------------------
     ci0 += BK;
-    if (ci0 >= a.Cin) { ci0 = 0; ++tapi; }
-    if (ks + 1 < k_end) gload(tapi, ci0);
+    if (ks + 1 < k_end) {
+      if (ci0 >= a.Cin) {
+        ci0 = 0; ++tapi;
+        if constexpr (!SMALLC && !X3) set_tap(tapi);
+      }
+      gload(tapi, ci0);
+    }
 
     if constexpr (X3) {
       // ---- 32 k's = 2 x (16-deep bf16 MFMA) x 6 plane pairs, smallest products first ----------

@@ -23,4 +23,4 @@ for cfg in sys.argv[1:] or [""]:
         k, v = kv.split("=")
         env[k] = v
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
-    print("%-48s us/it, checksum:" % (cfg or "(default)"), out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-400:], flush=True)
+    print("%-48s us/it, checksum:" % (cfg or "(default)"), (out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-400:]), out.stderr.strip()[-200:] if os.environ.get("SWEEP_STDERR") else "", flush=True)
