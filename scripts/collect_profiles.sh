@@ -13,6 +13,7 @@ python scripts/perf_configs.py f32 > $O/configs.txt 2>&1
 python scripts/pmc_traffic.py $O/pmc_f $O/pmc_w $O/pmc_traffic.json $COMMIT > /dev/null
 python scripts/pmc_kernels.py collect $O/pmc_kernels > $O/pmc_kernels.txt 2>&1
 cp $O/prof_roofline/*/*kernel_stats.csv $O/roofline_leg_kernel_stats.csv
+python scripts/timeline_from_trace.py $(ls $O/prof_graph/*/*kernel_trace.csv) 100 > $O/timeline_iteration.txt 2>&1
 cp $O/prof_graph/*/*kernel_stats.csv $O/graph_its200_kernel_stats.csv
 rm -rf $O/pmc_f $O/pmc_w $O/pmc_kernels/sq $O/pmc_kernels/lds $O/pmc_kernels/fetch $O/pmc_kernels/write
 ls $O
