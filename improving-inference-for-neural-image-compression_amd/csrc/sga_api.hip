@@ -100,6 +100,7 @@ struct sga_handle {
   int run_B = 0, run_H = 0, run_W = 0, run_its = -1, run_it = 0;   // sga_run_begin/steps state
   float run_lambda = 0.f, run_loss_scale = 1.f; uint64_t run_seed = 0;
   bool split256 = true;            // split-K also for a single-phase launch of exactly 256 tiles (SGA_SPLIT256=0: off)
+  bool plan_tiles = true;          // tile height / extra split by estimated grid efficiency (SGA_PLAN_TILES=0: round-2 rules only)
   bool fused_mse = true;           // distortion sums + gradient image in gs3.fwd's epilogue (SGA_FUSED_MSE=0: separate k_mse)
   bool fused_post = true;          // IGDN as the post-phase of the producing convolution launch (SGA_FUSED_POST=0: off)
   bool fused_gdn = true;           // gdn_fused.hip instead of the stand-alone GDN launches (SGA_FUSED_GDN=0: off)
@@ -153,6 +154,23 @@ namespace {
     if (_s != SGA_OK) return _s;     \
   } while (0)
 
+// Estimated fraction of the MFMA peak a launch of `n` equal workgroups of `bm`-row tiles reaches: resident
+// workgroups per CU (3 / 2 / 1 for 64 / 128 / 256 rows), the rate a CU sustains with that many (measured at
+// cfg 2: 64-row 2/CU 0.79-0.80, 128-row 2/CU 0.80, 256-row 0.79-0.82; one 4-wave workgroup alone 0.55-0.62),
+// and the quantisation of n into rounds of 256 x resident.  Kodak, 3 images: gs2.bwd as 576 128-row tiles
+// measured 0.51 (estimate 0.45), as 1152 64-row tiles the estimate is 0.63.
+double grid_efficiency(int bm, long long n) {
+  const int per_cu = bm == 64 ? 3 : (bm == 128 ? 2 : 1);
+  static const double R64[4] = {0, 0.55, 0.80, 0.84}, R128[3] = {0, 0.62, 0.80}, R256[2] = {0, 0.82};
+  long long c = (n + 255) / 256;
+  if (c > per_cu) c = per_cu;
+  if (c < 1) c = 1;
+  const double r = bm == 64 ? R64[c] : (bm == 128 ? R128[c] : R256[c]);
+  const long long slots = 256 * c;
+  const long long rounds = (n + slots - 1) / slots;
+  return r * (double)n / (double)(rounds * slots);
+}
+
 // Split-K factor for a launch whose tile grid under-fills the chip (256 CUs): spread the K walk
 // of each tile over S workgroups so that ~2 workgroups per CU are resident and the serial
 // K-chain per workgroup is S times shorter (deterministic slab reduce afterwards).
@@ -163,15 +181,29 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   if (a.out_coff != 0 || a.out_cs != a.Cout || (a.Cout & 3)) return 1;
   const int tiles = a.tiles_per_phase * a.ntiles_n;
   const int blocks = a.nphase * tiles;
-  if (blocks > 256 || (blocks == 256 && a.nphase == 1 && !h->split256)) return 1;
-  // target: ~512 workgroups of (nearly) equal K length
+  int target = 512;      // ~512 workgroups of (nearly) equal K length
+  if (blocks > 256 || (blocks == 256 && a.nphase == 1 && !h->split256)) {
+    // More than one workgroup per CU but fewer than the CUs can hold at once (64-row tiles: 3 per CU): some
+    // CUs run one workgroup more than others and set the launch's time.  Split along K when the estimate
+    // says the fuller grid pays for its slabs (e.g. gs2.bwd of one Kodak image: 384 tiles -> 768 workgroups).
+    if (!h->plan_tiles || a.bm != 64) return 1;
+    const double e1 = grid_efficiency(64, blocks);
+    int best = 1;
+    double eb = e1;
+    for (int S = 2; S <= 3; ++S) {
+      const double e = grid_efficiency(64, (long long)blocks * S) * 0.93;
+      if (e > eb * 1.05) { eb = e; best = S; }
+    }
+    if (best == 1) return 1;
+    target = blocks * best;
+  }
   long long total_steps = 0;
   int steps[4] = {0, 0, 0, 0};
   for (int p = 0; p < a.nphase; ++p) {
     steps[p] = a.ph[p].ntaps * (a.Cin / 32);
     total_steps += (long long)steps[p] * tiles;
   }
-  int T = (int)((total_steps + 511) / 512);      // K-steps per workgroup
+  int T = (int)((total_steps + target - 1) / target);      // K-steps per workgroup
   if (T < 2) T = 2;
   const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
   const long long cap = (long long)h->cur_part->cap / n_out;
@@ -207,20 +239,39 @@ struct PostGdn {
 
 // every MFMA convolution goes through here (so it can be timed)
 int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nullptr, PostGdn* post = nullptr) {
-  // 256-row tile (8 waves): each weight byte feeds twice the MFMAs; only for big unsplit f32 launches
+  // Tile height.  128 rows (4 waves, 2 workgroups/CU) is the general instance; f32 launches with all 192
+  // output channels in one tile can also run 256-row tiles (8 waves, 1/CU: each weight byte feeds twice the
+  // MFMAs, and the IGDN can run as its post-phase) or 64-row tiles (3/CU: twice the tiles for grids that
+  // under-fill the chip).  Rules tuned at cfg 2: >= 1024 128-row tiles -> 256 rows, <= 256 -> 64 rows.  In
+  // between (Kodak / Tecnick shapes) the height whose grid quantises best into rounds of resident
+  // workgroups wins (grid_efficiency): e.g. 576 128-row tiles = 1.1 rounds, as 1152 64-row tiles 1.5.
   a.bm = 128;
-  if (h->bm256 && !h->x3 && !a.smallc && a.pro == PRO_NONE && a.Npad / a.ntiles_n == 192 &&
-      (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RELU_MASK) &&
-      (long long)a.nphase * a.tiles_per_phase * a.ntiles_n >= 1024) {
-    a.bm = 256;
-    a.tiles_per_phase = (a.tiles_per_phase + 1) / 2;
-  }
-  // 64-row tile (4 waves, 3 workgroups/CU) for launches whose 128-row grid under-fills the chip
-  if (h->bm64_max > 0 && !h->x3 && !a.smallc && a.pro == PRO_NONE && a.Npad / a.ntiles_n == 192 &&
-      (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RELU_MASK) &&
-      (long long)a.nphase * a.tiles_per_phase * a.ntiles_n <= h->bm64_max) {
-    a.bm = 64;
-    a.tiles_per_phase = cdiv(a.B * a.Hg * a.Wg, 64);
+  const bool variants = !h->x3 && !a.smallc && a.pro == PRO_NONE && a.Npad / a.ntiles_n == 192 &&
+                        (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RELU_MASK);
+  if (variants) {
+    const long long rows = (long long)a.B * a.Hg * a.Wg;
+    const long long n128 = (long long)a.nphase * cdiv(rows, 128) * a.ntiles_n;
+    const long long n64 = (long long)a.nphase * cdiv(rows, 64) * a.ntiles_n;
+    const long long n256 = (long long)a.nphase * cdiv(rows, 256) * a.ntiles_n;
+    int bm = 128;
+    if (h->bm64_max > 0 && n128 <= h->bm64_max) bm = 64;
+    else if (h->bm256 && n128 >= 1024 && !h->plan_tiles) bm = 256;
+    else if (h->plan_tiles) {
+      double e = grid_efficiency(128, n128);
+      if (h->bm256 && n128 >= 512) {
+        // a 256-row launch that also does the IGDN (POST) saves the IGDN launch: ~17 % of the pair's time
+        const bool with_post = post && h->fused_post && a.Cout == 192 && a.Npad == 192 && a.epi == EPI_BIAS &&
+                               a.out_coff == 0 && a.out_cs == 192 && post->s_out && post->v_out;
+        const double e256 = grid_efficiency(256, n256) * (with_post ? 1.17 : 1.0);
+        if (e256 >= e) { e = e256; bm = 256; }
+      }
+      if (h->bm64_max > 0) {
+        const double e64 = grid_efficiency(64, n64);
+        if (e64 > e * 1.03) { e = e64; bm = 64; }
+      }
+    }
+    a.bm = bm;
+    a.tiles_per_phase = (int)cdiv(rows, bm);
   }
   a.ksplit = pick_ksplit(h, a);
   {
@@ -1164,6 +1215,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->fused_gdn = !(env && env[0] == '0');
   env = getenv("SGA_FUSED_POST");
   h->fused_post = !(env && env[0] == '0');
+  env = getenv("SGA_PLAN_TILES");
+  h->plan_tiles = !(env && env[0] == '0');
   env = getenv("SGA_FUSED_MSE");
   h->fused_mse = !(env && env[0] == '0');
   env = getenv("SGA_NO_SPLITK");
