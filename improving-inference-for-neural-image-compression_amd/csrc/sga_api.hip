@@ -181,21 +181,26 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   if (a.out_coff != 0 || a.out_cs != a.Cout || (a.Cout & 3)) return 1;
   const int tiles = a.tiles_per_phase * a.ntiles_n;
   const int blocks = a.nphase * tiles;
-  int target = 512;      // ~512 workgroups of (nearly) equal K length
-  if (blocks > 256 || (blocks == 256 && a.nphase == 1 && !h->split256)) {
-    // More than one workgroup per CU but fewer than the CUs can hold at once (64-row tiles: 3 per CU): some
-    // CUs run one workgroup more than others and set the launch's time.  Split along K when the estimate
-    // says the fuller grid pays for its slabs (e.g. gs2.bwd of one Kodak image: 384 tiles -> 768 workgroups).
-    if (!h->plan_tiles || a.bm != 64) return 1;
-    const double e1 = grid_efficiency(64, blocks);
+  int target = 512;      // ~512 workgroups of (nearly) equal K length (tuned at cfg 2)
+  const int bn = a.Npad / a.ntiles_n;
+  const bool big = blocks > 256 || (blocks == 256 && a.nphase == 1 && !h->split256);
+  // Where the cfg-2 rule does not reach -- grids of more than 256 blocks that still quantise badly into
+  // rounds of resident workgroups (gs2.bwd of one Kodak image: 384 64-row tiles for 768 slots; of one
+  // Tecnick image: 704 128-row tiles = 1.4 rounds of 512), and 128-row launches in general (176 tiles x 3 =
+  // 528 workgroups is two rounds) -- the split is the multiple S of the grid with the best estimated
+  // efficiency, each extra slab priced at 3.5 %.
+  const bool search = h->plan_tiles && ((a.bm == 64 && big) || (a.bm == 128 && blocks > 128 && (bn == 192 || bn == 256)));
+  if (search) {
     int best = 1;
-    double eb = e1;
-    for (int S = 2; S <= 3; ++S) {
-      const double e = grid_efficiency(64, (long long)blocks * S) * 0.93;
+    double eb = grid_efficiency(a.bm, blocks);
+    for (int S = 2; S <= 8; ++S) {
+      const double e = grid_efficiency(a.bm, (long long)blocks * S) / (1.0 + 0.035 * (S - 1));
       if (e > eb * 1.05) { eb = e; best = S; }
     }
     if (best == 1) return 1;
     target = blocks * best;
+  } else if (big) {
+    return 1;
   }
   long long total_steps = 0;
   int steps[4] = {0, 0, 0, 0};
