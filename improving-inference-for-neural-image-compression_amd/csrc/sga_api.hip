@@ -122,6 +122,8 @@ struct sga_handle {
   hipGraphExec_t graph_exec = nullptr;
   bool side_last = true;           // graph capture: create the hyper branch's nodes after the main chain's (SGA_SIDE_LAST=0: before)
   int graph_B = 0, graph_H = 0, graph_W = 0, graph_relax = 0;
+  hipGraphExec_t bb_graph[2] = {nullptr, nullptr};   // one iteration of bits-back stage 1 / stage 2
+  int bb_graph_B = 0, bb_graph_H = 0, bb_graph_W = 0;
   int relax = 0, sched = 0;        // sga_set_relaxation
   int use_graph = 1;
 
@@ -992,6 +994,7 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
 
 void free_all(sga_handle* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  for (int k = 0; k < 2; ++k) if (h->bb_graph[k]) (void)hipGraphExecDestroy(h->bb_graph[k]);
   for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1757,6 +1760,39 @@ int bb_eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_ha
   return SGA_OK;
 }
 
+// `n` replays of one bits-back iteration (stage 0 / 1) as a hipGraph captured once per geometry: the step context
+// lives on the device and every launch argument is a workspace pointer, so an iteration is the same launch
+// sequence whatever its number (as in sga_run_steps).  Eager when graphs are off or a profile is being taken.
+template <typename F>
+int bb_iterations(sga_handle* h, int stage, const Geom& g, int n, hipStream_t st, F&& enqueue) {
+  bool graphed = false;
+  if (h->use_graph && !h->profiling && n > 0) {
+    if (h->bb_graph_B != g.B || h->bb_graph_H != g.H || h->bb_graph_W != g.W) {
+      for (int k = 0; k < 2; ++k)
+        if (h->bb_graph[k]) { (void)hipGraphExecDestroy(h->bb_graph[k]); h->bb_graph[k] = nullptr; }
+      h->bb_graph_B = g.B; h->bb_graph_H = g.H; h->bb_graph_W = g.W;
+    }
+    if (!h->bb_graph[stage]) {
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const int rc = enqueue();
+        const hipError_t ec = hipStreamEndCapture(st, &graph);
+        if (!(rc == SGA_OK && ec == hipSuccess && graph &&
+              hipGraphInstantiate(&h->bb_graph[stage], graph, nullptr, nullptr, 0) == hipSuccess))
+          h->bb_graph[stage] = nullptr;
+        if (graph) (void)hipGraphDestroy(graph);
+      }
+      (void)hipGetLastError();
+    }
+    graphed = h->bb_graph[stage] != nullptr;
+  }
+  for (int it = 0; it < n; ++it) {
+    if (graphed) HIPCHK(h, hipGraphLaunch(h->bb_graph[stage], st));
+    else SGACHK(enqueue());
+  }
+  return SGA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1840,13 +1876,14 @@ int sga_bb_run(sga_handle* h, const float* x, int B, int H, int W, float lambda,
   HIPCHK(h, launch_fill(h->vzml.p, 0.f, (int64_t)(nz2), st));
   HIPCHK(h, launch_fill((float*)h->sums, 0.f, (int64_t)(sizeof(ImgSums) / sizeof(float)) * (B), st));
   HIPCHK(h, launch_set_ctx(h->ctx, -1, its, 0.f, 0.f, lambda, loss_scale, seed, st));
-  for (int it = 0; it < its; ++it) {
+  SGACHK(bb_iterations(h, 0, g, its, st, [&]() -> int {
     HIPCHK(h, launch_advance_ctx(h->ctx, h->Ttab.p, h->lrtab.p, st));
     SGACHK(bb_step_core(h, g, h->xin.p, h->y.p, h->zml.p, nullptr, nullptr, false, 1, st));
     HIPCHK(h, launch_adam_latent(h->y.p, h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, h->my.p, h->vy.p, ny, h->ctx, st));
     HIPCHK(h, launch_adam_ctx(h->zml.p, h->g_zml.p, h->mzml.p, h->vzml.p, nz2, h->ctx, st));
     HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, nullptr, nullptr, h->trace.p, st));
-  }
+    return SGA_OK;
+  }));
   if (trace1 && its > 0)
     HIPCHK(h, launch_copy(trace1, h->trace.p, (int64_t)((size_t)its * 4), st));
   // ---- stage 2: fix y_tilde = round(y), rate optimisation of zml (bb_sga.py:238-261) ----------
@@ -1856,12 +1893,13 @@ int sga_bb_run(sga_handle* h, const float* x, int B, int H, int W, float lambda,
   HIPCHK(h, launch_fill(h->mzml.p, 0.f, (int64_t)(nz2), st));
   HIPCHK(h, launch_fill(h->vzml.p, 0.f, (int64_t)(nz2), st));
   HIPCHK(h, launch_set_ctx(h->ctx, -1, r_its, 1.f, 0.f, 0.f, loss_scale, seed, st));
-  for (int it = 0; it < r_its; ++it) {
+  SGACHK(bb_iterations(h, 1, g, r_its, st, [&]() -> int {
     HIPCHK(h, launch_advance_ctx(h->ctx, h->Ttab.p, h->lrtab2.p, st));
     SGACHK(bb_step_core(h, g, nullptr, h->yt.p, h->zml.p, nullptr, nullptr, true, 2, st));
     HIPCHK(h, launch_adam_ctx(h->zml.p, h->g_zml.p, h->mzml.p, h->vzml.p, nz2, h->ctx, st));
     HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, nullptr, nullptr, h->trace.p, st));
-  }
+    return SGA_OK;
+  }));
   if (trace2 && r_its > 0)
     HIPCHK(h, launch_copy(trace2, h->trace.p, (int64_t)((size_t)r_its * 4), st));
   if (zml_out) HIPCHK(h, launch_copy(zml_out, h->zml.p, (int64_t)(nz2), st));
