@@ -573,6 +573,11 @@ struct ReduceArgs {
   const float* bias; const float* aux0; float* out;
 };
 
+// BATCH: the loads of 8 slabs are issued together and only the adds are serial (same order, same result).  A
+// 75-slab reduce is otherwise a chain of 75 dependent L2 round trips (20 us against 3).  Used on the main
+// chain; the hyper branch on the second stream keeps the serial form: at cfg 2 the faster reduce there makes
+// `hs2.bwd` ready exactly when `gs2.fwd` starts and the ITERATION 70 us slower.
+template <bool BATCH>
 __global__ void splitk_reduce_kernel(const ReduceArgs r) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < r.n4;
        i += (long long)gridDim.x * blockDim.x) {
@@ -585,7 +590,21 @@ __global__ void splitk_reduce_kernel(const ReduceArgs r) {
       S = r.nsplit[(oy & 1) * 2 + (ox & 1)];
     }
     f32x4 acc = ld4(r.part + e);
-    for (int s = 1; s < S; ++s) acc += ld4(r.part + (size_t)s * r.slab + e);   // fixed order
+    if constexpr (BATCH) {
+      for (int s = 1; s < S; s += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int sk = s + k < S ? s + k : S - 1;
+          v[k] = ld4(r.part + (size_t)sk * r.slab + e);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (s + k < S) acc += v[k];                                            // fixed order
+      }
+    } else {
+      for (int s = 1; s < S; ++s) acc += ld4(r.part + (size_t)s * r.slab + e);   // fixed order
+    }
     if ((r.epi == EPI_BIAS || r.epi == EPI_BIAS_RELU) && r.bias) acc += ld4(r.bias + c);
     if (r.epi == EPI_BIAS_RELU) {
 #pragma unroll
@@ -683,7 +702,8 @@ int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream) {
   long long g = (r.n4 + 255) / 256;
   if (g > 4096) g = 4096;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, r);
+  if (a.reduce_batch) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)g), dim3(256), 0, stream, r);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((unsigned)g), dim3(256), 0, stream, r);
   return (int)hipGetLastError();
 }
 

@@ -281,6 +281,8 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     a.tiles_per_phase = (int)cdiv(rows, bm);
   }
   a.ksplit = pick_ksplit(h, a);
+  { static const int rb = getenv("SGA_REDUCE_BATCH") ? atoi(getenv("SGA_REDUCE_BATCH")) : 1;
+    a.reduce_batch = rb == 2 ? 1 : (rb == 1 ? (h->cur_part == &h->part) : 0); }
   {
     const long long blocks = (long long)a.nphase * a.tiles_per_phase * a.ntiles_n;
     const int per_cu = a.bm == 64 ? 3 : (a.bm == 128 ? 2 : 1);

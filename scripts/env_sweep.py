@@ -1,4 +1,4 @@
-"""GPU box: us per SGA iteration (bench shape, graph replay) under different environment knobs.
+"""GPU box: us per SGA iteration (bench shape, or C/B/H/W from the environment; graph replay) under different environment knobs.
 usage: python scripts/env_sweep.py "" "SGA_GRAPH_UNROLL=4" "A=1;B=2" ..."""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,8 +7,9 @@ import os, sys, time
 sys.path.insert(0, %r)
 import torch, sga_amd
 from sga_amd.codec import SGACodec
-c = SGACodec(sga_amd.make_synthetic_weights(192, 0), 192, 8, 256, 256)
-x = torch.rand(8, 256, 256, 3, generator=torch.Generator().manual_seed(1000)).cuda()
+C, B, H, W = (int(os.environ.get(k, d)) for k, d in (('C', 192), ('B', 8), ('H', 256), ('W', 256)))
+c = SGACodec(sga_amd.make_synthetic_weights(C, 0), C, B, H, W)
+x = torch.rand(B, H, W, 3, generator=torch.Generator().manual_seed(1000)).cuda()
 y, z = c.encode(x)
 c.run(x, 0.01, its=40, metrics=False); torch.cuda.synchronize()
 best = 1e9
