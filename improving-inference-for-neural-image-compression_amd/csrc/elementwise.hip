@@ -51,6 +51,56 @@ __device__ __forceinline__ float sgnf(float t) { return (t > 0.f) - (t < 0.f); }
 //   v_tilde = floor*s0 + ceil*s1
 // floor/ceil carry no gradient; clip passes gradient inside [-1+eps, 1-eps].
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sample_one(float x, int64_t idx, const float* __restrict__ u, float T, int it,
+                                           unsigned k0, unsigned k1, int stream_id, int mode,
+                                           const int* __restrict__ img_ids, int64_t per_img,
+                                           float& vt_out, float& dvt_out) {
+  float u0, u1;
+  if (u) {
+    u0 = u[2 * idx];
+    u1 = u[2 * idx + 1];
+  } else {
+    uint32_t r[4];
+    // counter = element index within the REFERENCE batch: image img_ids[b] of it (sga_set_image_ids),
+    // so a shard draws the noise its images would have drawn in the un-sharded batch
+    int64_t ctr = idx;
+    if (img_ids) {
+      const int64_t b = idx / per_img;
+      ctr = (int64_t)img_ids[b] * per_img + (idx - b * per_img);
+    }
+    philox4x32_10((uint32_t)ctr, (uint32_t)((uint64_t)ctr >> 32), (uint32_t)it,
+                  (uint32_t)stream_id, k0, k1, r);
+    u0 = bits_to_uniform(r[0]);
+    u1 = bits_to_uniform(r[1]);
+  }
+  if (mode >= 2) {   // unoise.py:76 / ste.py:78 (identity STE) / map.py: unit Jacobian
+    vt_out = mode == 2 ? x + (u0 - 0.5f) : (mode == 3 ? rintf(x) : x);
+    dvt_out = 1.0f;
+    return;
+  }
+  const float fl = floorf(x), ce = ceilf(x);
+  const float rdn = x - fl, rup = ce - x;
+  const float lo = -1.0f + kEps, hi = 1.0f - kEps;
+  const float ddn = fminf(fmaxf(rdn, lo), hi);
+  const float dup = fminf(fmaxf(rup, lo), hi);
+  const float ldn = -atanhf(ddn) / T;
+  const float lup = -atanhf(dup) / T;
+  const float g0 = -logf(-logf(u0));
+  const float g1 = -logf(-logf(u1));
+  // danneal.py:83-84: plain softmax of the logits (no noise, no second division by T)
+  const float a0 = mode == 1 ? ldn : (ldn + g0) / T, a1 = mode == 1 ? lup : (lup + g1) / T;
+  const float mx = fmaxf(a0, a1);
+  const float e0 = expf(a0 - mx), e1 = expf(a1 - mx);
+  const float den = e0 + e1;
+  const float s0 = e0 / den, s1 = e1 / den;
+  vt_out = fl * s0 + ce * s1;
+  const float mdn = (rdn >= lo && rdn <= hi) ? 1.0f : 0.0f;
+  const float mup = (rup >= lo && rup <= hi) ? 1.0f : 0.0f;
+  // d(a1 - a0)/dv = (1/T^2) * ( mup/(1-dup^2) + mdn/(1-ddn^2) )
+  const float dd = (mup / (1.0f - dup * dup) + mdn / (1.0f - ddn * ddn)) / (mode == 1 ? T : T * T);
+  dvt_out = (ce - fl) * s0 * s1 * dd;
+}
+
 __device__ __forceinline__ void sample_range(const float* __restrict__ v, const float* __restrict__ u,
                          const StepCtx* __restrict__ ctx, int stream_id, float* __restrict__ vt,
                          float* __restrict__ dvt, int64_t n, int mode,
@@ -60,53 +110,10 @@ __device__ __forceinline__ void sample_range(const float* __restrict__ v, const 
   const unsigned k0 = ctx->seed_lo, k1 = ctx->seed_hi;
   for (int64_t idx = (int64_t)bid * blockDim.x + threadIdx.x; idx < n;
        idx += (int64_t)nblk * blockDim.x) {
-    float u0, u1;
-    if (u) {
-      u0 = u[2 * idx];
-      u1 = u[2 * idx + 1];
-    } else {
-      uint32_t r[4];
-      // counter = element index within the REFERENCE batch: image img_ids[b] of it (sga_set_image_ids),
-      // so a shard draws the noise its images would have drawn in the un-sharded batch
-      int64_t ctr = idx;
-      if (img_ids) {
-        const int64_t b = idx / per_img;
-        ctr = (int64_t)img_ids[b] * per_img + (idx - b * per_img);
-      }
-      philox4x32_10((uint32_t)ctr, (uint32_t)((uint64_t)ctr >> 32), (uint32_t)it,
-                    (uint32_t)stream_id, k0, k1, r);
-      u0 = bits_to_uniform(r[0]);
-      u1 = bits_to_uniform(r[1]);
-    }
-    const float x = v[idx];
-    if (mode >= 2) {   // unoise.py:76 / ste.py:78 (identity STE) / map.py: unit Jacobian
-      vt[idx] = mode == 2 ? x + (u0 - 0.5f) : (mode == 3 ? rintf(x) : x);
-      if (dvt) dvt[idx] = 1.0f;
-      continue;
-    }
-    const float fl = floorf(x), ce = ceilf(x);
-    const float rdn = x - fl, rup = ce - x;
-    const float lo = -1.0f + kEps, hi = 1.0f - kEps;
-    const float ddn = fminf(fmaxf(rdn, lo), hi);
-    const float dup = fminf(fmaxf(rup, lo), hi);
-    const float ldn = -atanhf(ddn) / T;
-    const float lup = -atanhf(dup) / T;
-    const float g0 = -logf(-logf(u0));
-    const float g1 = -logf(-logf(u1));
-    // danneal.py:83-84: plain softmax of the logits (no noise, no second division by T)
-    const float a0 = mode == 1 ? ldn : (ldn + g0) / T, a1 = mode == 1 ? lup : (lup + g1) / T;
-    const float mx = fmaxf(a0, a1);
-    const float e0 = expf(a0 - mx), e1 = expf(a1 - mx);
-    const float den = e0 + e1;
-    const float s0 = e0 / den, s1 = e1 / den;
-    vt[idx] = fl * s0 + ce * s1;
-    if (dvt) {
-      const float mdn = (rdn >= lo && rdn <= hi) ? 1.0f : 0.0f;
-      const float mup = (rup >= lo && rup <= hi) ? 1.0f : 0.0f;
-      // d(a1 - a0)/dv = (1/T^2) * ( mup/(1-dup^2) + mdn/(1-ddn^2) )
-      const float dd = (mup / (1.0f - dup * dup) + mdn / (1.0f - ddn * ddn)) / (mode == 1 ? T : T * T);
-      dvt[idx] = (ce - fl) * s0 * s1 * dd;
-    }
+    float a, d;
+    sample_one(v[idx], idx, u, T, it, k0, k1, stream_id, mode, img_ids, per_img, a, d);
+    vt[idx] = a;
+    if (dvt) dvt[idx] = d;
   }
 }
 
@@ -621,10 +628,75 @@ __global__ void k_check_int(const int* __restrict__ p, int expected, int* __rest
   if (*p != expected) atomicAdd(bad, 1);
 }
 
+__device__ __forceinline__ void finalize_step_body(ImgSums* sums, StepCtx* __restrict__ ctx, int B, int H,
+                                                   int W, float* scalars, float* psnr, float* trace,
+                                                   const float* __restrict__ Ttab, const float* __restrict__ lrtab);
+
 __global__ void k_finalize_step(ImgSums* sums, StepCtx* __restrict__ ctx, int B, int H,
                                 int W, float* scalars, float* psnr, float* trace,
                                 const float* __restrict__ Ttab, const float* __restrict__ lrtab) {
   if (threadIdx.x != 0) return;
+  finalize_step_body(sums, ctx, B, H, W, scalars, psnr, trace, Ttab, lrtab);
+}
+
+// The boundary between two SGA iterations in ONE launch: Adam on (y, z) with this iteration's gradients
+// (adam.py:40-56), the relaxation of the updated latents for the NEXT iteration (sga.py:86-98, 111-121: its
+// temperature Ttab[it + 1] and Philox counter it + 1 are read from the tables, not from the context), and --
+// by the workgroup that finishes last (ticket counter), after every workgroup has read the context -- the
+// per-iteration scalars and the context of the next iteration (k_finalize_step).  Same arithmetic as
+// k_adam_latent_yz / k_sample_yz / k_finalize_step launched one after the other: bit-identical.
+__global__ void k_step_boundary(float* __restrict__ py, const float* __restrict__ gay, const float* __restrict__ gby,
+                                float* __restrict__ jy, float* __restrict__ my, float* __restrict__ vy,
+                                float* __restrict__ yt, int64_t ny, float* __restrict__ pz,
+                                const float* __restrict__ gaz, const float* __restrict__ gbz,
+                                float* __restrict__ jz, float* __restrict__ mz, float* __restrict__ vz,
+                                float* __restrict__ zt, int64_t nz, StepCtx* __restrict__ ctx, int gy, int mode,
+                                const int* __restrict__ img_ids, int B, int H, int W, ImgSums* sums,
+                                float* trace, const float* __restrict__ Ttab, const float* __restrict__ lrtab,
+                                unsigned* __restrict__ ticket) {
+  __shared__ int last;
+  {
+    const float lr_t = ctx->lr_t;
+    const int it_n = ctx->it + 1;
+    const float T_n = it_n < ctx->its ? Ttab[it_n] : ctx->T;
+    const unsigned k0 = ctx->seed_lo, k1 = ctx->seed_hi;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.999);
+    const bool isy = (int)blockIdx.x < gy;
+    float* p = isy ? py : pz; const float* ga = isy ? gay : gaz; const float* gb = isy ? gby : gbz;
+    float* jac = isy ? jy : jz; float* m = isy ? my : mz; float* v = isy ? vy : vz; float* vt = isy ? yt : zt;
+    const int64_t n = isy ? ny : nz;
+    const int bid = isy ? blockIdx.x : blockIdx.x - gy, nblk = isy ? gy : gridDim.x - gy;
+    for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < n; i += (int64_t)nblk * blockDim.x) {
+      float s = ga[i];
+      if (gb) s += gb[i];
+      const float g = s * jac[i];
+      float pp = p[i], mm = m[i], vv = v[i];
+      adam_update(pp, g, mm, vv, lr_t, b1, omb1, b2, omb2, eps);
+      p[i] = pp; m[i] = mm; v[i] = vv;
+      float a, d;
+      sample_one(pp, i, nullptr, T_n, it_n, k0, k1, isy ? 0 : 1, mode, img_ids, n / B, a, d);
+      vt[i] = a;
+      jac[i] = d;
+    }
+  }
+  // No fences: what must be ordered is every workgroup's READ of the context before the last one's WRITE of it.
+  // A workgroup takes its ticket after the barrier that follows its loop, i.e. after its context values have
+  // been consumed; the relaxed device-scope atomic orders the tickets; the writes below only have to be visible
+  // to the next kernel.  (A device-scope release per workgroup = an L2 write-back each: 50 us for this launch.)
+  __syncthreads();
+  if (threadIdx.x == 0)
+    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    finalize_step_body(sums, ctx, B, H, W, nullptr, nullptr, trace, Ttab, lrtab);
+    *ticket = 0;
+  }
+}
+
+__device__ __forceinline__ void finalize_step_body(ImgSums* sums, StepCtx* __restrict__ ctx, int B, int H,
+                                                   int W, float* scalars, float* psnr, float* trace,
+                                                   const float* __restrict__ Ttab, const float* __restrict__ lrtab) {
   const double npx = (double)H * W;
   const double ls = ctx->loss_scale;
   double sq = 0.0, nats = 0.0, ps = 0.0;
@@ -866,6 +938,24 @@ int launch_finalize_step(ImgSums* sums, StepCtx* ctx, int B, int H, int W, float
                          float* psnr, float* trace, hipStream_t s, const float* Ttab, const float* lrtab) {
   hipLaunchKernelGGL(k_finalize_step, dim3(1), dim3(64), 0, s, sums, ctx, B, H, W, scalars, psnr,
                      trace, Ttab, lrtab);
+  LAUNCH_RET();
+}
+
+int launch_step_boundary(float* py, const float* gay, const float* gby, float* jy, float* my, float* vy, float* yt,
+                         int64_t ny, float* pz, const float* gaz, const float* gbz, float* jz, float* mz, float* vz,
+                         float* zt, int64_t nz, StepCtx* ctx, int mode, const int* img_ids, int B, int H, int W,
+                         ImgSums* sums, float* trace, const float* Ttab, const float* lrtab, unsigned* ticket,
+                         hipStream_t s) {
+  // at most 512 workgroups: each ends with an atomic on ONE address (1632 of them serialise to 25 us), while
+  // fewer than ~400 leave the relaxation's long dependent chains (Philox, log, atanh, exp) too little parallelism
+  int gy = grid_for(ny), gz = grid_for(nz);
+  const int cap = 512;
+  if (gy + gz > cap) {
+    gz = gz > cap / 8 ? cap / 8 : gz;
+    gy = gy > cap - gz ? cap - gz : gy;
+  }
+  hipLaunchKernelGGL(k_step_boundary, dim3(gy + gz), dim3(256), 0, s, py, gay, gby, jy, my, vy, yt, ny, pz, gaz, gbz,
+                     jz, mz, vz, zt, nz, ctx, gy, mode, img_ids, B, H, W, sums, trace, Ttab, lrtab, ticket);
   LAUNCH_RET();
 }
 

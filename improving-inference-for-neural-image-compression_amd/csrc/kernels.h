@@ -71,6 +71,13 @@ int launch_advance_ctx(StepCtx* ctx, const float* Ttab, const float* lrtab, hipS
 int launch_finalize_step(ImgSums* sums, StepCtx* ctx, int B, int H, int W, float* scalars,
                          float* psnr, float* trace, hipStream_t s, const float* Ttab = nullptr,
                          const float* lrtab = nullptr);
+// Adam of this iteration + relaxation for the next + per-iteration scalars / context advance in one launch
+// (k_step_boundary); `ticket`: a zero-initialised device counter owned by the handle
+int launch_step_boundary(float* py, const float* gay, const float* gby, float* jy, float* my, float* vy, float* yt,
+                         int64_t ny, float* pz, const float* gaz, const float* gbz, float* jz, float* mz, float* vz,
+                         float* zt, int64_t nz, StepCtx* ctx, int mode, const int* img_ids, int B, int H, int W,
+                         ImgSums* sums, float* trace, const float* Ttab, const float* lrtab, unsigned* ticket,
+                         hipStream_t s);
 // the y and z relaxations / Adam updates of one SGA iteration in one launch each (Philox noise only)
 int launch_sample_yz(const float* y, float* yt, float* dyt, int64_t ny, const float* z, float* zt, float* dzt,
                      int64_t nz, const StepCtx* ctx, int mode, const int* img_ids, int B, hipStream_t s);

@@ -75,6 +75,8 @@ struct sga_handle {
   float* gs_bias[4] = {nullptr}; float* gs_beta[3] = {nullptr};
   float* ha_bias[3] = {nullptr}; float* hs_bias[3] = {nullptr};
   float* eb_packed = nullptr;
+  unsigned* ticket = nullptr;      // k_step_boundary's last-workgroup counter (zero between launches)
+  bool fused_boundary = true;      // SGA_FUSED_BOUNDARY=0: Adam, relaxation and finalize as three launches
   float* gs3_halo_w = nullptr;   // C->3 layer packed for deconv3.hip: [C/32][9][16][32]
   bool gs3_generic = false;      // SGA_GS3_GENERIC=1: use the generic gather-GEMM for the C->3 layer
   std::vector<void*> owned;      // every hipMalloc'd block
@@ -1162,6 +1164,12 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     if (msssim_init() != 0) return fail(SGA_ERR_HIP);
   }
   TRY(alloc_buf(h, h->scratch, 8 + B * 8));
+  {
+    void* p = nullptr;
+    TRY(dev_alloc(h, &p, 256));
+    if (hipMemset(p, 0, 256) != hipSuccess) return fail(SGA_ERR_HIP);
+    h->ticket = (unsigned*)p;
+  }
   TRY(alloc_buf(h, h->part, (size_t)48 << 20));      // 192 MiB
   TRY(alloc_buf(h, h->partB, (size_t)8 << 20));      // 32 MiB
   h->cur_part = &h->part;
@@ -1227,6 +1235,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->fused_post = !(env && env[0] == '0');
   env = getenv("SGA_PLAN_TILES");
   h->plan_tiles = !(env && env[0] == '0');
+  env = getenv("SGA_FUSED_BOUNDARY");
+  h->fused_boundary = !(env && env[0] == '0');
   env = getenv("SGA_FUSED_MSE");
   h->fused_mse = !(env && env[0] == '0');
   env = getenv("SGA_NO_SPLITK");
@@ -1389,7 +1399,23 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
                            h->run_loss_scale, h->run_seed, st));
   HIPCHK(h, launch_fill((float*)h->sums, 0.f, (int64_t)(sizeof(ImgSums) / sizeof(float)) * (B), st));
 
+  // One iteration = forward/backward on the relaxed latents that are already in the workspace, then ONE launch
+  // for Adam, the relaxation for the next iteration and the scalars / context advance (k_step_boundary).  The
+  // relaxation of the first iteration of this call is launched here (counter-based noise: re-drawing it after
+  // another entry point used the workspace gives the same values).
+  const bool fb = h->fused_boundary && !(h->dump);
+  if (fb)
+    HIPCHK(h, launch_sample_yz(h->y.p, h->yt.p, h->dyt.p, ny, h->z.p, h->zt.p, h->dzt.p, nz, h->ctx, h->relax,
+                               h->img_ids, B, st));
   auto enqueue_step = [&](hipStream_t s) -> int {
+    if (fb) {
+      SGACHK(rd_forward_backward(h, g, h->xin.p, true, s));
+      HIPCHK(h, launch_step_boundary(h->y.p, h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, h->my.p, h->vy.p, h->yt.p, ny,
+                                     h->z.p, h->g_zt_hs.p, h->g_zt_eb.p, h->dzt.p, h->mz.p, h->vz.p, h->zt.p, nz,
+                                     h->ctx, h->relax, h->img_ids, B, H, W, h->sums, h->trace.p, h->Ttab.p,
+                                     h->lrtab.p, h->ticket, s));
+      return SGA_OK;
+    }
     SGACHK(sga_step_core(h, g, h->xin.p, h->y.p, h->z.p, nullptr, nullptr, s));
     HIPCHK(h, launch_adam_latent_yz(h->y.p, h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, h->my.p, h->vy.p, ny,
                                     h->z.p, h->g_zt_hs.p, h->g_zt_eb.p, h->dzt.p, h->mz.p, h->vz.p, nz, h->ctx, s));

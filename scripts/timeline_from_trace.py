@@ -6,7 +6,10 @@ def short(n):
     n = re.sub(r'\(anonymous namespace\)::', '', n); n = re.sub(r'\(.*$', '', n); n = n.replace('void ', '')
     return n[:58]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_sample_yz' in r['Kernel_Name']]      # first launch of an iteration
+idx = [i + 1 for i, r in enumerate(rows) if 'k_step_boundary' in r['Kernel_Name']]      # the launch after the last one of an iteration
+if len(idx) < 20:
+    idx = [i for i, r in enumerate(rows) if 'k_sample_yz' in r['Kernel_Name']]      # SGA_FUSED_BOUNDARY=0: first launch of an iteration
+idx = [i for i in idx if i < len(rows)]
 its = [(int(rows[idx[k + 1]]['Start_Timestamp']) - int(rows[idx[k]]['Start_Timestamp'])) / 1e3 for k in range(10, len(idx) - 2)]
 print("iterations", len(idx), "mean us/it", sum(its) / len(its), "min", min(its))
 i0, i1 = idx[which], idx[which + 1]

@@ -96,3 +96,30 @@ def test_distortion_in_the_gs3_epilogue_equals_the_separate_kernel(C, B, H, W):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert torch.allclose(a[2][:, :4], b[2][:, :4], rtol=1e-6, atol=0, equal_nan=True)
     fused.close(); plain.close()
+
+
+@pytest.mark.parametrize("C,B,H,W", [(64, 2, 64, 64), (128, 3, 37, 41), (192, 2, 256, 256)])
+def test_step_boundary_kernel_equals_the_three_launches(C, B, H, W):
+    """Adam (adam.py:40-56), the relaxation of the next iteration (sga.py:86-98, 111-121) and the per-iteration
+    scalars / context advance as ONE launch (k_step_boundary) vs three (SGA_FUSED_BOUNDARY=0): the same
+    arithmetic per element, so latents, metrics and the per-iteration trace agree BIT FOR BIT -- also when the
+    run is cut into pieces with other entry points using the workspace in between, and for a sibling relaxation."""
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    one = _codec_env("SGA_FUSED_BOUNDARY", "1", w, C, B, H, W)
+    three = _codec_env("SGA_FUSED_BOUNDARY", "0", w, C, B, H, W)
+    x = np.random.RandomState(C + H).rand(B, H, W, 3).astype(np.float32)
+    a = one.run(x, 0.01, its=60, seed=5, trace=True)
+    b = three.run(x, 0.01, its=60, seed=5, trace=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[2].nan_to_num(), b[2].nan_to_num())
+    assert torch.equal(a[3], b[3])                                   # [its, 4] per-iteration trace
+    # in pieces, with an evaluation (which overwrites the relaxed latents in the workspace) in between
+    one.run_begin(x, 0.01, its=60, seed=5)
+    one.run_steps(17)
+    y, z = one.run_latents()
+    one.evaluate(x, torch.round(y), torch.round(z))
+    one.run_steps(43)
+    y, z, tr = one.run_latents(trace=True)
+    assert torch.equal(torch.round(y), a[0]) and torch.equal(torch.round(z), a[1])
+    assert torch.equal(tr[:60], a[3])
+    one.close(); three.close()
