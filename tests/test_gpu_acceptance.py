@@ -25,9 +25,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL_BPP, TOL_PSNR = 1e-3, 0.01          # north_star tolerance
 
 
-def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir):
+# the small set (C = 64, 4 x 64^2, 32 seeds) and one at the north star's width (C = 192, 2 x 128^2, 16 seeds)
+@pytest.mark.parametrize("golden", ["full_run_oracle.json", "full_run_oracle_c192.json"])
+def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir, golden):
     from sga_amd.codec import SGACodec, metrics_to_dict
-    with open(os.path.join(ROOT, "tests", "golden", "full_run_oracle.json")) as f:
+    with open(os.path.join(ROOT, "tests", "golden", golden)) as f:
         gold = json.load(f)
     cfg = gold["config"]
     C, B, H, W = cfg["C"], cfg["B"], cfg["H"], cfg["W"]
@@ -56,7 +58,7 @@ def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir)
                oracle_seed_std_bpp=spread["est_bpp_std_per_image"],
                hip_seed_std_psnr=np.array(hip_psnr).std(0, ddof=1).tolist(),
                oracle_seed_std_psnr=spread["psnr_std_per_image"])
-    with open(os.path.join(gpu_out_dir, "acceptance_full_run.json"), "w") as f:
+    with open(os.path.join(gpu_out_dir, golden.replace("full_run_oracle", "acceptance_full_run")), "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps(rep))
     # the north-star tolerance, on the means (standard errors stated in the report: ~3e-4 bpp, ~1e-3 dB)

@@ -10,7 +10,7 @@ The trajectories are chaotic in the last float32 bits (a rounding difference fli
 decision, after which the two runs are different samples of the same stochastic optimiser), so the
 criterion is statistical: this script also records the oracle's own seed-to-seed spread.
 
-    python tests/tools/make_golden_full_run.py            # ~8 min on 4 cores
+    python tests/tools/make_golden_full_run.py            # ~8 min on 4 cores (the small set)
 """
 import json
 import os
@@ -20,9 +20,15 @@ from multiprocessing import Pool
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-OUT = os.path.join(ROOT, "tests", "golden", "full_run_oracle.json")
-
-CFG = dict(C=64, B=4, H=64, W=64, its=2000, lmbda=0.01, x_seed=6, weight_seed=0, seeds=list(range(32)))
+# two sets: the small one (C = 64, 4 x 64^2, 32 seeds) and one at the north star's width (C = 192, 2 x 128^2,
+# 16 seeds; ~14 min per seed on one core):  GOLDEN=c192 NPROC=7 python tests/tools/make_golden_full_run.py
+CFGS = {
+    "": dict(C=64, B=4, H=64, W=64, its=2000, lmbda=0.01, x_seed=6, weight_seed=0, seeds=list(range(32))),
+    "c192": dict(C=192, B=2, H=128, W=128, its=2000, lmbda=0.01, x_seed=7, weight_seed=0, seeds=list(range(16))),
+}
+NAME = os.environ.get("GOLDEN", "")
+CFG = CFGS[NAME]
+OUT = os.path.join(ROOT, "tests", "golden", "full_run_oracle%s.json" % ("_" + NAME if NAME else ""))
 
 
 def make_inputs(cfg):
