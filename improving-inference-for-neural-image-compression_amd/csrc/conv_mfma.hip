@@ -65,6 +65,24 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2& h, u32x2& m, u32x2&
   l.y = cvt_pk_bf16(r2 - bf16_lo(m.y), r3 - bf16_hi(m.y));
 }
 
+// Instances whose K loop takes its operands by LDS-DMA (global_load_lds_dwordx4): see the GLDS block in conv_tile
+constexpr bool glds_instance(int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3, int POST) {
+  // 64-row (2 x 32 KB stages, still 2 workgroups/CU) and 256-row (2 x 56 KB, 1/CU either way).  The 128-row 4-wave
+  // instances would drop to one workgroup per CU with two stages and keep the register-staged loop; so does the
+  // 2-wave BN = 96 instance of the hyper branch (same speed alone, but with 56 KB per workgroup it gets in the
+  // main chain's way: the iteration measured 1868 against 1827 us)
+  return !X3 && !SMALLC && PRO == PRO_NONE &&
+         ((POST == 0 && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2));
+}
+
+// 16 bytes per lane, global memory -> LDS at `lds_dst` (wave-uniform) + lane * 16, no registers in between.
+// (The builtin only exists in the device pass; the host pass needs the kernel template to stay instantiable.)
+__device__ __forceinline__ void dma16_to_lds(const float* src, float* lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // POST = 1 (256-row tile, BN = C = 192 only): the IGDN that follows the transposed convolution
@@ -81,7 +99,8 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   constexpr int PX = (PRO == PRO_IGDN_BWD) ? PA : 1;
 
   constexpr int CPITCH = TN * 32 + 4;         // epilogue staging pitch (floats) per wave row
-  constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (BM + BN) * LDK;
+  constexpr bool GLDS = glds_instance(TM, TN, WM, WN, PRO, SMALLC, X3, POST);
+  constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (GLDS ? 2 * (BM + BN) * 32 : (BM + BN) * LDK);
   constexpr int EPI_FLOATS = WM * WN * 32 * CPITCH;
   constexpr int POST_FLOATS = POST ? (128 * (BN + 4) + 2 * BN * LDK) : 0;
   constexpr int LDS_FLOATS0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
     k_end = (int)((long long)(split + 1) * nsteps_all / nsplit);
   }
   int tapi = k_begin / nchunk, ci0 = (k_begin - tapi * nchunk) * BK;
-  if (k_begin < k_end) {
+  if (k_begin < k_end && !GLDS) {
     if constexpr (!SMALLC && !X3) set_tap(tapi);
     gload(tapi, ci0);
   }
@@ -270,6 +289,107 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   const int brow = (wn * TN) * 32 + (lane & 31);
   const int koff = (lane >> 5) * 4;
 
+  // ---- GLDS (f32 instances of glds_instance): operands by LDS-DMA ---------------------------------------------------------
+  // `global_load_lds_dwordx4` moves 16 bytes per lane from global memory straight into LDS: no staging
+  // registers, no ds_write, and with two LDS stages one barrier per K-step (the loads of step k+1 are issued at
+  // the top of step k and have the whole step to land; `__syncthreads` waits for them).  A DMA instruction
+  // writes its 64 lanes' pieces contiguously, so a stage is unpadded 128-byte rows; the bank conflicts that the
+  // 144-byte pitch avoided are avoided by an XOR swizzle instead: lane slot j of row r loads K-chunk
+  // j ^ ((r >> 1) & 7), and the fragment reads apply the same XOR.  Taps outside the image read a zero page.
+  // Same operands, same MFMA order: bit-identical to the register-staged loop (micro-benchmark: +4 %).
+  if constexpr (GLDS) {
+    constexpr int STAGE = (BM + BN) * 32;                  // floats per stage
+    constexpr int NW = WM * WN;
+    constexpr int IA = BM / (NW * 8), IB = BN / (NW * 8);  // DMA instructions per wave: 8 rows x 8 slots each
+    static_assert(BM % (NW * 8) == 0 && BN % (NW * 8) == 0, "LDS-DMA row split");
+    const int slot = lane & 7, r8 = lane >> 3;
+    // A rows of this lane: tile row wid*(BM/NW) + p*8 + r8
+    int g_iy[IA], g_ix[IA], g_base[IA], g_chunk[IA];
+#pragma unroll
+    for (int p = 0; p < IA; ++p) {
+      const int r = wid * (BM / NW) + p * 8 + r8;
+      const int m = m0 + r;
+      g_chunk[p] = (slot ^ ((r >> 1) & 7)) * 4;
+      if (m < Mtot) {
+        const int j = m % a.Wg;
+        const int t = m / a.Wg;
+        g_iy[p] = (t % a.Hg) * a.s_in; g_ix[p] = j * a.s_in; g_base[p] = (t / a.Hg) * a.Hin * a.Win;
+      } else {
+        g_iy[p] = -(1 << 20); g_ix[p] = 0; g_base[p] = 0;
+      }
+    }
+    int gb_chunk[IB];
+#pragma unroll
+    for (int p = 0; p < IB; ++p) {
+      const int r = BM + wid * (BN / NW) + p * 8 + r8;     // stage row of this weight row
+      gb_chunk[p] = (slot ^ ((r >> 1) & 7)) * 4;
+    }
+    const float* ga_src[IA];                               // per tap: address of the row's piece at channel 0
+    const float* gb_src[IB];
+    auto tap_setup = [&](int t) {
+      const ConvTap tp = a.taps[ph.tap_begin + t];
+#pragma unroll
+      for (int p = 0; p < IA; ++p) {
+        const int iy = g_iy[p] + tp.dy, ix = g_ix[p] + tp.dx;
+        const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        ga_src[p] = ok ? a.in + ((size_t)(g_base[p] + iy * a.Win + ix) * a.in_cs + a.in_coff + g_chunk[p]) : nullptr;
+      }
+#pragma unroll
+      for (int p = 0; p < IB; ++p)
+        gb_src[p] = a.w + (((size_t)tp.slab * a.Npad + n0 + wid * (BN / NW) + p * 8 + r8) * a.Cin + gb_chunk[p]);
+    };
+    const int lds_a = __builtin_amdgcn_readfirstlane(wid * (BM / NW) * 32);
+    const int lds_b = __builtin_amdgcn_readfirstlane((BM + wid * (BN / NW)) * 32);
+    auto issue = [&](int stage, int ci) {
+      float* st = smem + stage * STAGE;
+#pragma unroll
+      for (int p = 0; p < IA; ++p)
+        dma16_to_lds(ga_src[p] ? ga_src[p] + ci : a.zeros, st + lds_a + p * 256);
+#pragma unroll
+      for (int p = 0; p < IB; ++p)
+        dma16_to_lds(gb_src[p] + ci, st + lds_b + p * 256);
+    };
+    if (k_begin < k_end) {
+      tap_setup(tapi);
+      issue(0, ci0);
+    }
+    __syncthreads();
+    const int ra_ = (wm * TM) * 32 + (lane & 31);
+    const int rb_ = BM + (wn * TN) * 32 + (lane & 31);
+    const int hlf = lane >> 5;
+    for (int ks = k_begin; ks < k_end; ++ks) {
+      const int cur = (ks - k_begin) & 1;
+      if (ks + 1 < k_end) {
+        ci0 += BK;
+        if (ci0 >= a.Cin) { ci0 = 0; ++tapi; tap_setup(tapi); }
+        issue(cur ^ 1, ci0);
+      }
+      const float* St = smem + cur * STAGE;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 2 * q + hlf;
+        f32x4 af[TM], bf[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int r = ra_ + tm * 32;
+          af[tm] = *reinterpret_cast<const f32x4*>(&St[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int r = rb_ + tn * 32;
+          bf[tn] = *reinterpret_cast<const f32x4*>(&St[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][r], bf[tn][r], acc[tm][tn], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  } else
   for (int ks = k_begin; ks < k_end; ++ks) {
     // ---- staged registers -> LDS (prologue transform fused here) ----------------------
     char* const smem_b = reinterpret_cast<char*>(smem);
@@ -622,7 +742,8 @@ template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3 = false,
 int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (BM + BN) * LDK;
+  constexpr bool GLDS = glds_instance(TM, TN, WM, WN, PRO, SMALLC, X3, POST);
+  constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (GLDS ? 2 * (BM + BN) * 32 : (BM + BN) * LDK);
   constexpr int EPI_FLOATS = WM * WN * 32 * (TN * 32 + 4);
   constexpr int POST_FLOATS = POST ? (128 * (BN + 4) + 2 * BN * LDK) : 0;
   constexpr int F0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;

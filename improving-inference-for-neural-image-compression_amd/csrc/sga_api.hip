@@ -75,6 +75,7 @@ struct sga_handle {
   float* gs_bias[4] = {nullptr}; float* gs_beta[3] = {nullptr};
   float* ha_bias[3] = {nullptr}; float* hs_bias[3] = {nullptr};
   float* eb_packed = nullptr;
+  float* zeros = nullptr;          // 256 zero bytes (ConvArgs::zeros)
   unsigned* ticket = nullptr;      // k_step_boundary's last-workgroup counter (zero between launches)
   bool fused_boundary = true;      // SGA_FUSED_BOUNDARY=0: Adam, relaxation and finalize as three launches
   float* gs3_halo_w = nullptr;   // C->3 layer packed for deconv3.hip: [C/32][9][16][32]
@@ -283,6 +284,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     a.tiles_per_phase = (int)cdiv(rows, bm);
   }
   a.ksplit = pick_ksplit(h, a);
+  a.zeros = h->zeros;
   { static const int rb = getenv("SGA_REDUCE_BATCH") ? atoi(getenv("SGA_REDUCE_BATCH")) : 1;
     a.reduce_batch = rb == 2 ? 1 : (rb == 1 ? (h->cur_part == &h->part) : 0); }
   {
@@ -1169,6 +1171,12 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     TRY(dev_alloc(h, &p, 256));
     if (hipMemset(p, 0, 256) != hipSuccess) return fail(SGA_ERR_HIP);
     h->ticket = (unsigned*)p;
+  }
+  {
+    void* p = nullptr;
+    TRY(dev_alloc(h, &p, 256));
+    if (hipMemset(p, 0, 256) != hipSuccess) return fail(SGA_ERR_HIP);
+    h->zeros = (float*)p;
   }
   TRY(alloc_buf(h, h->part, (size_t)48 << 20));      // 192 MiB
   TRY(alloc_buf(h, h->partB, (size_t)8 << 20));      // 32 MiB
