@@ -72,7 +72,8 @@ constexpr bool glds_instance(int TM, int TN, int WM, int WN, int PRO, bool SMALL
   // 2-wave BN = 96 instance of the hyper branch (same speed alone, but with 56 KB per workgroup it gets in the
   // main chain's way: the iteration measured 1868 against 1827 us)
   return !X3 && !SMALLC && PRO == PRO_NONE &&
-         ((POST == 0 && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2));
+         ((POST == 0 && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2) ||
+          (POST == 0 && TM == 2 && TN == 4 && WM == 4 && WN == 2));
 }
 
 // 16 bytes per lane, global memory -> LDS at `lds_dst` (wave-uniform) + lane * 16, no registers in between.
@@ -846,7 +847,12 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
         return launch_inst<2, 3, 4, 2, PRO_NONE, false>(a, stream);
       }
       return launch_pro<2, 3, 2, 2>(a, stream);
-    case 256: return launch_pro<2, 4, 2, 2>(a, stream);
+    case 256:
+      if (a.bm == 256) {      // C = 256: 8 waves, 256 x 256 tile, LDS-DMA loop
+        if (a.smallc || a.pro != PRO_NONE || a.x3 || a.post) return (int)hipErrorInvalidValue;
+        return launch_inst<2, 4, 4, 2, PRO_NONE, false>(a, stream);
+      }
+      return launch_pro<2, 4, 2, 2>(a, stream);
     case 64: return launch_pro<2, 1, 2, 2>(a, stream);
     case 96:
       if (a.smallc || a.pro != PRO_NONE) return (int)hipErrorInvalidValue;

@@ -176,6 +176,19 @@ double grid_efficiency(int bm, long long n) {
   return r * (double)n / (double)(rounds * slots);
 }
 
+// Best split multiple S <= 8 of a grid of `blocks` tiles by the same estimate, each extra slab priced at 3.5 %
+// (S = 1 unless a split wins by 5 %); returns the estimate.
+double best_split(int bm, long long blocks, int* S_out) {
+  int best = 1;
+  double eb = grid_efficiency(bm, blocks);
+  for (int S = 2; S <= 8; ++S) {
+    const double e = grid_efficiency(bm, blocks * S) / (1.0 + 0.035 * (S - 1));
+    if (e > eb * 1.05) { eb = e; best = S; }
+  }
+  if (S_out) *S_out = best;
+  return eb;
+}
+
 // Split-K factor for a launch whose tile grid under-fills the chip (256 CUs): spread the K walk
 // of each tile over S workgroups so that ~2 workgroups per CU are resident and the serial
 // K-chain per workgroup is S times shorter (deterministic slab reduce afterwards).
@@ -197,11 +210,7 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   const bool search = h->plan_tiles && ((a.bm == 64 && big) || (a.bm == 128 && blocks > 128 && (bn == 192 || bn == 256)));
   if (search) {
     int best = 1;
-    double eb = grid_efficiency(a.bm, blocks);
-    for (int S = 2; S <= 8; ++S) {
-      const double e = grid_efficiency(a.bm, (long long)blocks * S) / (1.0 + 0.035 * (S - 1));
-      if (e > eb * 1.05) { eb = e; best = S; }
-    }
+    (void)best_split(a.bm, blocks, &best);
     if (best == 1) return 1;
     target = blocks * best;
   } else if (big) {
@@ -267,7 +276,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     if (h->bm64_max > 0 && n128 <= h->bm64_max) bm = 64;
     else if (h->bm256 && n128 >= 1024 && !h->plan_tiles) bm = 256;
     else if (h->plan_tiles) {
-      double e = grid_efficiency(128, n128);
+      double e = best_split(128, n128, nullptr);
       if (h->bm256 && n128 >= 512) {
         // a 256-row launch that also does the IGDN (POST) saves the IGDN launch: ~17 % of the pair's time
         const bool with_post = post && h->fused_post && a.Cout == 192 && a.Npad == 192 && a.epi == EPI_BIAS &&
@@ -276,12 +285,24 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
         if (e256 >= e) { e = e256; bm = 256; }
       }
       if (h->bm64_max > 0) {
-        const double e64 = grid_efficiency(64, n64);
+        const double e64 = n64 > 256 ? best_split(64, n64, nullptr) : grid_efficiency(64, n64);
         if (e64 > e * 1.03) { e = e64; bm = 64; }
       }
     }
     a.bm = bm;
     a.tiles_per_phase = (int)cdiv(rows, bm);
+  }
+  // C = 256 (BN = 256): 128-row tiles (register-staged loop) or 256-row tiles (8 waves, LDS-DMA loop)
+  if (h->plan_tiles && h->bm256 && !h->x3 && !a.smallc && a.pro == PRO_NONE && a.Npad / a.ntiles_n == 256 &&
+      (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RELU_MASK)) {
+    const long long rows = (long long)a.B * a.Hg * a.Wg;
+    const long long n128 = (long long)a.nphase * cdiv(rows, 128) * a.ntiles_n;
+    const long long n256 = (long long)a.nphase * cdiv(rows, 256) * a.ntiles_n;
+    const double bonus = 1.04;      // the LDS-DMA loop against the register-staged 128-row one
+    if (n128 >= 512 && grid_efficiency(256, n256) * bonus >= best_split(128, n128, nullptr)) {
+      a.bm = 256;
+      a.tiles_per_phase = (int)cdiv(rows, 256);
+    }
   }
   a.ksplit = pick_ksplit(h, a);
   a.zeros = h->zeros;
