@@ -831,6 +831,7 @@ int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream) {
 
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
   const int bn = a.Npad / a.ntiles_n;
+  if ((a.bm == 64 || a.bm == 256) && !a.zeros) return (int)hipErrorInvalidValue;   // LDS-DMA instances read the zero page
   switch (bn) {
     case 192:
       if (a.bm == 64) {
