@@ -289,6 +289,10 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   const int arow = (wm * TM) * 32 + (lane & 31);
   const int brow = (wn * TN) * 32 + (lane & 31);
   const int koff = (lane >> 5) * 4;
+#ifdef SGA_CLOCK_PROBE
+  unsigned long long clk0 = 0, wall0 = 0;
+  if (a.clk) { clk0 = __builtin_readcyclecounter(); wall0 = wall_clock64(); }
+#endif
 
   // ---- GLDS (f32 instances of glds_instance): operands by LDS-DMA ---------------------------------------------------------
   // `global_load_lds_dwordx4` moves 16 bytes per lane from global memory straight into LDS: no staging
@@ -487,6 +491,17 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
     __syncthreads();
   }
 
+#ifdef SGA_CLOCK_PROBE
+  if (a.clk && tid == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.clk[4 * blockIdx.x] = __builtin_readcyclecounter() - clk0;
+    a.clk[4 * blockIdx.x + 1] = wall_clock64() - wall0;
+    a.clk[4 * blockIdx.x + 2] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+    a.clk[4 * blockIdx.x + 3] = wall0;
+  }
+#endif
   // ---- epilogue -------------------------------------------------------------------------------
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
   const int half = lane >> 5, col = lane & 31;

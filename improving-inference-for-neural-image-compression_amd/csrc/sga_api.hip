@@ -5,6 +5,7 @@
 #include <cstring>
 #include <functional>
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/sga_hip.h"
@@ -76,6 +77,11 @@ struct sga_handle {
   float* ha_bias[3] = {nullptr}; float* hs_bias[3] = {nullptr};
   float* eb_packed = nullptr;
   float* zeros = nullptr;          // 256 zero bytes (ConvArgs::zeros)
+  unsigned long long* clk_probe = nullptr;   // SGA_CLOCK_PROBE=1|2 (measurement): [slot][16384][2] ticks, see ConvArgs::clk
+  int clk_mode = 0;                          // 1: per-layer profiling runs (host reads after every launch);
+                                             // 2: launches captured into the step graph, read once at sga_destroy
+  struct ClkSlot { char name[96]; int grid; };
+  std::vector<ClkSlot> clk_slots;
   unsigned* ticket = nullptr;      // k_step_boundary's last-workgroup counter (zero between launches)
   bool fused_boundary = true;      // SGA_FUSED_BOUNDARY=0: Adam, relaxation and finalize as three launches
   float* gs3_halo_w = nullptr;   // C->3 layer packed for deconv3.hip: [C/32][9][16][32]
@@ -306,6 +312,14 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   }
   a.ksplit = pick_ksplit(h, a);
   a.zeros = h->zeros;
+#ifdef SGA_CLOCK_PROBE
+  a.clk = (h->clk_mode == 1 && h->profiling && h->profile_by_layer) ? h->clk_probe : nullptr;
+  if (h->clk_mode == 2 && h->clk_slots.size() < 40) {
+    hipStreamCaptureStatus ccs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &ccs);
+    if (ccs == hipStreamCaptureStatusActive) a.clk = h->clk_probe + h->clk_slots.size() * (size_t)(4 * 16384);
+  }
+#endif
   { static const int rb = getenv("SGA_REDUCE_BATCH") ? atoi(getenv("SGA_REDUCE_BATCH")) : 1;
     a.reduce_batch = rb == 2 ? 1 : (rb == 1 ? (h->cur_part == &h->part) : 0); }
   {
@@ -344,6 +358,31 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     HIPCHK(h, hipEventRecord(r.a, st));
   }
   HIPCHK(h, launch_conv(a, st));
+#ifdef SGA_CLOCK_PROBE
+  if (a.clk && h->clk_mode == 2) {
+    sga_handle::ClkSlot cs;
+    int grid = 0;
+    for (int p = 0; p < a.nphase; ++p) grid += a.tiles_per_phase * a.ntiles_n * (a.ksplit > 1 ? a.nsplit[p] : 1);
+    cs.grid = grid > 16384 ? 16384 : grid;
+    char kn[64];
+    conv_kernel_name(a, kn, sizeof(kn));
+    snprintf(cs.name, sizeof(cs.name), "%s %s k%d", h->cur_tag, kn + 16, a.ksplit);
+    h->clk_slots.push_back(cs);
+  } else if (a.clk) {      // measurement: shader clock sustained inside this launch's K loops (wall_clock64 ticks at 100 MHz)
+    int grid = 0;
+    for (int p = 0; p < a.nphase; ++p) grid += a.tiles_per_phase * a.ntiles_n * (a.ksplit > 1 ? a.nsplit[p] : 1);
+    if (grid > 16384) grid = 16384;
+    std::vector<unsigned long long> t(4 * (size_t)grid);
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipMemcpy(t.data(), h->clk_probe, t.size() * sizeof(t[0]), hipMemcpyDeviceToHost));
+    double c = 0, w = 0;
+    for (int i = 0; i < grid; ++i) { c += (double)t[4 * i]; w += (double)t[4 * i + 1]; }
+    char kn[64];
+    conv_kernel_name(a, kn, sizeof(kn));
+    fprintf(stderr, "clock_probe %s %s k%d grid %d: %.0f MHz in the K loop\n", h->cur_tag, kn + 16, a.ksplit, grid,
+            w > 0 ? 100.0 * c / w : 0.0);
+  }
+#endif
   if (h->profiling && !h->profile_by_layer) {   // symbol-level stats: the conv kernel alone
     HIPCHK(h, hipEventRecord(r.b, st));
     h->prof.push_back(r);
@@ -1198,6 +1237,16 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     TRY(dev_alloc(h, &p, 256));
     if (hipMemset(p, 0, 256) != hipSuccess) return fail(SGA_ERR_HIP);
     h->zeros = (float*)p;
+#ifdef SGA_CLOCK_PROBE
+    if (const char* e = getenv("SGA_CLOCK_PROBE")) {
+      h->clk_mode = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0);
+      if (h->clk_mode) {
+        void* q = nullptr;
+        TRY(dev_alloc(h, &q, (size_t)40 * 16384 * 4 * sizeof(unsigned long long)));
+        h->clk_probe = (unsigned long long*)q;
+      }
+    }
+#endif
   }
   TRY(alloc_buf(h, h->part, (size_t)48 << 20));      // 192 MiB
   TRY(alloc_buf(h, h->partB, (size_t)8 << 20));      // 32 MiB
@@ -1280,6 +1329,25 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
 int sga_destroy(sga_handle* h) {
   if (!h) return SGA_ERR_BAD_ARG;
   (void)hipDeviceSynchronize();
+  if (h->clk_mode == 2) {      // measurement: clocks of the LAST replay of the captured step
+    std::vector<unsigned long long> t(4 * 16384);
+    for (size_t s = 0; s < h->clk_slots.size(); ++s) {
+      if (hipMemcpy(t.data(), h->clk_probe + s * (size_t)(4 * 16384), t.size() * sizeof(t[0]), hipMemcpyDeviceToHost) != hipSuccess) break;
+      double c = 0, w = 0, wmin = 1e30, wmax = 0;
+      for (int i = 0; i < h->clk_slots[s].grid; ++i) {
+        c += (double)t[4 * i]; w += (double)t[4 * i + 1];
+        wmin = std::min(wmin, (double)t[4 * i + 1]); wmax = std::max(wmax, (double)t[4 * i + 1]);
+      }
+      const int g = h->clk_slots[s].grid;
+      if (const char* dir = getenv("SGA_CLOCK_PROBE_DUMP")) {      // raw [grid][4] u64: cycles, wall, hw_id | xcc_id << 32, start
+        char fn[512];
+        snprintf(fn, sizeof(fn), "%s/clk_slot_%02zu.bin", dir, s);
+        if (FILE* f = fopen(fn, "wb")) { fwrite(t.data(), sizeof(t[0]), 4 * (size_t)g, f); fclose(f); }
+      }
+      fprintf(stderr, "clock_probe(graph) %s grid %d: %.0f MHz in the K loop; K loop per workgroup mean %.1f us, min %.1f, max %.1f\n",
+              h->clk_slots[s].name, g, w > 0 ? 100.0 * c / w : 0.0, w / g / 100.0, wmin / 100.0, wmax / 100.0);
+    }
+  }
   free_all(h);
   delete h;
   return SGA_OK;

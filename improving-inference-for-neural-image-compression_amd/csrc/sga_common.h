@@ -85,6 +85,10 @@ struct ConvArgs {
   // fused IGDN post-phase (256-row unsplit C = 192 launches): out = u, post_s = sqrt(n), post_v = u * sqrt(n)
   int post; const float* post_w; const float* post_beta; float* post_s; float* post_v;
   const float* zeros;      // >= 256 bytes of zeros: what taps outside the image load (LDS-DMA instance)
+#ifdef SGA_CLOCK_PROBE     // measurement build only (make PROBE=1): keeps the production kernels and their arguments unchanged
+  unsigned long long* clk; // measurement only (SGA_CLOCK_PROBE=1, else null): per workgroup, shader-clock and 100 MHz
+                           //   wall-clock ticks spent in the K loop -> the clock the chip sustains under this kernel
+#endif
   int reduce_batch;        // split-K reduce: issue the slab loads 8 at a time (main chain) or one by one
   int pair_phases;         // 4-phase launch whose whole grid is resident at once: walk the phases as 9,6,4,6 taps
   int bm;                  // rows per tile: 128 (default, 4 waves) or 256 (8 waves, big unsplit layers)

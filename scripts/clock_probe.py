@@ -1,0 +1,27 @@
+"""GPU box, measurement build (make -C <pkg>/csrc clean; make -C <pkg>/csrc PROBE=1): shader clock and per-workgroup
+K-loop time inside the convolution launches of the graph-replayed SGA iteration (bench shape).
+    python scripts/clock_probe.py [its] > profiles/rNN_clock_probe.txt
+Every conv workgroup records readcyclecounter / wall_clock64 (100 MHz) ticks around its K loop plus HW_ID / XCC_ID;
+the values of the LAST replay are read back when the handle is destroyed (csrc/sga_api.hip, SGA_CLOCK_PROBE=2)."""
+import os, sys, glob, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+dump = tempfile.mkdtemp()
+os.environ["SGA_CLOCK_PROBE"] = "2"; os.environ["SGA_CLOCK_PROBE_DUMP"] = dump
+import numpy as np, torch, sga_amd
+from sga_amd.codec import SGACodec
+its = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+C, B, H, W = 192, 8, 256, 256
+c = SGACodec(sga_amd.make_synthetic_weights(C, 0), C, B, H, W)
+x = torch.rand(B, H, W, 3, generator=torch.Generator().manual_seed(1000)).cuda()
+c.run(x, 0.01, its=its, seed=7, metrics=False); torch.cuda.synchronize()
+c.close()      # prints one "clock_probe(graph) <layer> ..." line per captured conv launch to stderr
+print("per-workgroup detail (launch order of the captured iteration; first = older workgroup of a CU pair):")
+for f in sorted(glob.glob(os.path.join(dump, "clk_slot_*.bin"))):
+    t = np.fromfile(f, dtype=np.uint64).reshape(-1, 4)
+    wall = t[:, 1].astype(float) / 100.0
+    mhz = 100.0 * t[:, 0].astype(float).sum() / t[:, 1].astype(float).sum()
+    xcc = (t[:, 2] >> np.uint64(32)).astype(np.int64) & 0xF
+    n = len(wall); h = n // 2
+    print(f"{os.path.basename(f)} n={n:5d} {mhz:5.0f} MHz  K loop us: mean {wall.mean():7.1f} min {wall.min():7.1f} max {wall.max():7.1f}"
+          f"  blocks[:n/2] {wall[:h].mean():7.1f}  blocks[n/2:] {wall[h:].mean():7.1f}  per XCC "
+          + " ".join(f"{wall[xcc == k].mean():.0f}" for k in range(8) if (xcc == k).any()))
