@@ -117,6 +117,12 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int chunk = tid & 7, lrow = tid >> 3;
+#ifdef SGA_CLOCK_PROBE
+  const unsigned long long wallE = a.clk ? wall_clock64() : 0;
+#define SGA_PROBE_END() do { if (a.clk && tid == 0) a.clk[6 * blockIdx.x + 5] = wall_clock64(); } while (0)
+#else
+#define SGA_PROBE_END() do { } while (0)
+#endif
 
   int bid = blockIdx.x;
   int split = 0, nsplit = 1, phase, mt, nt;
@@ -496,10 +502,11 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
     unsigned hwid, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    a.clk[4 * blockIdx.x] = __builtin_readcyclecounter() - clk0;
-    a.clk[4 * blockIdx.x + 1] = wall_clock64() - wall0;
-    a.clk[4 * blockIdx.x + 2] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
-    a.clk[4 * blockIdx.x + 3] = wall0;
+    a.clk[6 * blockIdx.x] = __builtin_readcyclecounter() - clk0;
+    a.clk[6 * blockIdx.x + 1] = wall_clock64() - wall0;
+    a.clk[6 * blockIdx.x + 2] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+    a.clk[6 * blockIdx.x + 3] = wall0;
+    a.clk[6 * blockIdx.x + 4] = wallE;
   }
 #endif
   // ---- epilogue -------------------------------------------------------------------------------
@@ -610,6 +617,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
       emit(a.post_s);                                // s
       lds_barrier();                                 // the tile is rewritten by the next half
     }
+    SGA_PROBE_END();
     return;
   }
   if (a.epi == EPI_SHUFFLE3 && a.ksplit <= 1) {
@@ -700,6 +708,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
     }
     __builtin_amdgcn_wave_barrier();
   }
+  SGA_PROBE_END();
 }
 
 struct ReduceArgs {

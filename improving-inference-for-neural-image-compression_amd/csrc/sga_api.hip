@@ -115,6 +115,7 @@ struct sga_handle {
   bool fused_gdn = true;           // gdn_fused.hip instead of the stand-alone GDN launches (SGA_FUSED_GDN=0: off)
   int bm64_max = 256;              // 64-row tiles when the 128-row grid has at most this many blocks (SGA_BM64_MAX; 0 = off)
   bool bm256 = true;               // 256-row 8-wave tile for big unsplit f32 launches (SGA_BM256=0: off)
+  bool bm256_split = true;         // ... and, split in two, for single-phase launches of 128 such tiles (SGA_BM256_SPLIT=0: off)
   int fork_at = 0;                 // main-chain launch index at which the hyper branch is forked (SGA_FORK_AT)
   int dbg_it = -1;                 // iteration being enqueued (SGA_DEBUG_DUMP)
   hipEvent_t ev_fork_cap = nullptr, ev_join_cap = nullptr;   // while `st` is being captured
@@ -205,7 +206,7 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   if (a.out_coff != 0 || a.out_cs != a.Cout || (a.Cout & 3)) return 1;
   const int tiles = a.tiles_per_phase * a.ntiles_n;
   const int blocks = a.nphase * tiles;
-  int target = 512;      // ~512 workgroups of (nearly) equal K length (tuned at cfg 2)
+  int target = a.bm == 256 ? 256 : 512;      // ~512 workgroups of (nearly) equal K length (tuned at cfg 2); 256-row: one per CU
   const int bn = a.Npad / a.ntiles_n;
   const bool big = blocks > 256 || (blocks == 256 && a.nphase == 1 && !h->split256);
   // Where the cfg-2 rule does not reach -- grids of more than 256 blocks that still quantise badly into
@@ -279,7 +280,13 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     const long long n64 = (long long)a.nphase * cdiv(rows, 64) * a.ntiles_n;
     const long long n256 = (long long)a.nphase * cdiv(rows, 256) * a.ntiles_n;
     int bm = 128;
-    if (h->bm64_max > 0 && n128 <= h->bm64_max) bm = 64;
+    // A single-phase launch of 128 (or 256) 256-row tiles: split in two (or not at all) it is exactly one
+    // 8-wave workgroup per CU, and that K loop runs at 0.90 of the MFMA peak against 0.84 for two 64-row
+    // workgroups per CU (in-kernel probe, profiles/r02_clock_probe.txt: 5.70 us per 256 x 192 x 32 step) --
+    // more than the second slab costs: gs2.bwd at cfg 2 467 -> 448 us, iteration 1834 -> 1823 us.
+    const bool one_per_cu = h->bm256_split && a.nphase == 1 && (n256 == 128 || n256 == 256);
+    if (one_per_cu) bm = 256;
+    else if (h->bm64_max > 0 && n128 <= h->bm64_max) bm = 64;
     else if (h->bm256 && n128 >= 1024 && !h->plan_tiles) bm = 256;
     else if (h->plan_tiles) {
       double e = best_split(128, n128, nullptr);
@@ -317,7 +324,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   if (h->clk_mode == 2 && h->clk_slots.size() < 40) {
     hipStreamCaptureStatus ccs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &ccs);
-    if (ccs == hipStreamCaptureStatusActive) a.clk = h->clk_probe + h->clk_slots.size() * (size_t)(4 * 16384);
+    if (ccs == hipStreamCaptureStatusActive) a.clk = h->clk_probe + h->clk_slots.size() * (size_t)(6 * 16384);
   }
 #endif
   { static const int rb = getenv("SGA_REDUCE_BATCH") ? atoi(getenv("SGA_REDUCE_BATCH")) : 1;
@@ -372,11 +379,11 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     int grid = 0;
     for (int p = 0; p < a.nphase; ++p) grid += a.tiles_per_phase * a.ntiles_n * (a.ksplit > 1 ? a.nsplit[p] : 1);
     if (grid > 16384) grid = 16384;
-    std::vector<unsigned long long> t(4 * (size_t)grid);
+    std::vector<unsigned long long> t(6 * (size_t)grid);
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipMemcpy(t.data(), h->clk_probe, t.size() * sizeof(t[0]), hipMemcpyDeviceToHost));
     double c = 0, w = 0;
-    for (int i = 0; i < grid; ++i) { c += (double)t[4 * i]; w += (double)t[4 * i + 1]; }
+    for (int i = 0; i < grid; ++i) { c += (double)t[6 * i]; w += (double)t[6 * i + 1]; }
     char kn[64];
     conv_kernel_name(a, kn, sizeof(kn));
     fprintf(stderr, "clock_probe %s %s k%d grid %d: %.0f MHz in the K loop\n", h->cur_tag, kn + 16, a.ksplit, grid,
@@ -1242,7 +1249,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
       h->clk_mode = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0);
       if (h->clk_mode) {
         void* q = nullptr;
-        TRY(dev_alloc(h, &q, (size_t)40 * 16384 * 4 * sizeof(unsigned long long)));
+        TRY(dev_alloc(h, &q, (size_t)40 * 16384 * 6 * sizeof(unsigned long long)));
         h->clk_probe = (unsigned long long*)q;
       }
     }
@@ -1301,6 +1308,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->split256 = !(env && env[0] == '0');
   env = getenv("SGA_BM256");
   h->bm256 = !(env && env[0] == '0');
+  env = getenv("SGA_BM256_SPLIT");
+  h->bm256_split = h->bm256 && !(env && env[0] == '0');
   env = getenv("SGA_BM64_MAX");
   if (env) h->bm64_max = atoi(env);
   env = getenv("SGA_FORK_AT");
@@ -1330,19 +1339,19 @@ int sga_destroy(sga_handle* h) {
   if (!h) return SGA_ERR_BAD_ARG;
   (void)hipDeviceSynchronize();
   if (h->clk_mode == 2) {      // measurement: clocks of the LAST replay of the captured step
-    std::vector<unsigned long long> t(4 * 16384);
+    std::vector<unsigned long long> t(6 * 16384);
     for (size_t s = 0; s < h->clk_slots.size(); ++s) {
-      if (hipMemcpy(t.data(), h->clk_probe + s * (size_t)(4 * 16384), t.size() * sizeof(t[0]), hipMemcpyDeviceToHost) != hipSuccess) break;
+      if (hipMemcpy(t.data(), h->clk_probe + s * (size_t)(6 * 16384), t.size() * sizeof(t[0]), hipMemcpyDeviceToHost) != hipSuccess) break;
       double c = 0, w = 0, wmin = 1e30, wmax = 0;
       for (int i = 0; i < h->clk_slots[s].grid; ++i) {
-        c += (double)t[4 * i]; w += (double)t[4 * i + 1];
-        wmin = std::min(wmin, (double)t[4 * i + 1]); wmax = std::max(wmax, (double)t[4 * i + 1]);
+        c += (double)t[6 * i]; w += (double)t[6 * i + 1];
+        wmin = std::min(wmin, (double)t[6 * i + 1]); wmax = std::max(wmax, (double)t[6 * i + 1]);
       }
       const int g = h->clk_slots[s].grid;
-      if (const char* dir = getenv("SGA_CLOCK_PROBE_DUMP")) {      // raw [grid][4] u64: cycles, wall, hw_id | xcc_id << 32, start
+      if (const char* dir = getenv("SGA_CLOCK_PROBE_DUMP")) {      // raw [grid][6] u64: K-loop cycles, K-loop wall ticks, hw_id | xcc_id << 32, wall at K-loop start, at entry, at exit
         char fn[512];
         snprintf(fn, sizeof(fn), "%s/clk_slot_%02zu.bin", dir, s);
-        if (FILE* f = fopen(fn, "wb")) { fwrite(t.data(), sizeof(t[0]), 4 * (size_t)g, f); fclose(f); }
+        if (FILE* f = fopen(fn, "wb")) { fwrite(t.data(), sizeof(t[0]), 6 * (size_t)g, f); fclose(f); }
       }
       fprintf(stderr, "clock_probe(graph) %s grid %d: %.0f MHz in the K loop; K loop per workgroup mean %.1f us, min %.1f, max %.1f\n",
               h->clk_slots[s].name, g, w > 0 ? 100.0 * c / w : 0.0, w / g / 100.0, wmin / 100.0, wmax / 100.0);

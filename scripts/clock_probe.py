@@ -17,11 +17,15 @@ c.run(x, 0.01, its=its, seed=7, metrics=False); torch.cuda.synchronize()
 c.close()      # prints one "clock_probe(graph) <layer> ..." line per captured conv launch to stderr
 print("per-workgroup detail (launch order of the captured iteration; first = older workgroup of a CU pair):")
 for f in sorted(glob.glob(os.path.join(dump, "clk_slot_*.bin"))):
-    t = np.fromfile(f, dtype=np.uint64).reshape(-1, 4)
+    t = np.fromfile(f, dtype=np.uint64).reshape(-1, 6)
+    pro = (t[:, 3].astype(float) - t[:, 4].astype(float)) / 100.0                          # entry -> K loop
+    epi = (t[:, 5].astype(float) - t[:, 3].astype(float) - t[:, 1].astype(float)) / 100.0  # K loop end -> exit
+    span = (t[:, 5].max() - t[:, 4].min()) / 100.0                                          # first entry -> last exit
     wall = t[:, 1].astype(float) / 100.0
     mhz = 100.0 * t[:, 0].astype(float).sum() / t[:, 1].astype(float).sum()
     xcc = (t[:, 2] >> np.uint64(32)).astype(np.int64) & 0xF
     n = len(wall); h = n // 2
     print(f"{os.path.basename(f)} n={n:5d} {mhz:5.0f} MHz  K loop us: mean {wall.mean():7.1f} min {wall.min():7.1f} max {wall.max():7.1f}"
           f"  blocks[:n/2] {wall[:h].mean():7.1f}  blocks[n/2:] {wall[h:].mean():7.1f}  per XCC "
-          + " ".join(f"{wall[xcc == k].mean():.0f}" for k in range(8) if (xcc == k).any()))
+          + " ".join(f"{wall[xcc == k].mean():.0f}" for k in range(8) if (xcc == k).any())
+          + f"  | prologue mean {pro.mean():.1f} max {pro.max():.1f}  after-K-loop mean {epi.mean():.1f} max {epi.max():.1f}  launch span {span:.1f}")
