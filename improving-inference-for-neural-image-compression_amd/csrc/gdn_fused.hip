@@ -58,6 +58,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
   const int half = lane >> 5, col = lane & 31, koff = half * 4;
   const long long m0 = (long long)blockIdx.x * BM;
   const float* __restrict__ gw = a.w;
+#ifdef SGA_CLOCK_PROBE
+#define GDN_STAMP(k) do { if (a.clk && tid == 0) a.clk[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+  if (a.clk && tid == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.clk[8 * blockIdx.x + 5] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+  }
+#else
+#define GDN_STAMP(k) do { } while (0)
+#endif
+  GDN_STAMP(0);
 
   f32x4 rb[PB];
   auto load_b = [&](const float* w, int kpitch, int k0) {
@@ -156,6 +168,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
     __syncthreads();
   }
 
+  GDN_STAMP(1);
   // first K-step of gamma: in flight during the fill (backward: after it -- its three input streams
   // leave no registers for it)
   if constexpr (MODE != GDN_IGDN_BWD) load_b(gw, C, 0);
@@ -248,6 +261,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  GDN_STAMP(2);
   // ---- C x C contraction with gamma, A resident in the tile ------------------------------------
   if constexpr (MODE == GDN_IGDN_BWD) load_b(gw, C, 0);
   zero_acc();
@@ -261,6 +275,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
   }
   acc_to_tile();
   __syncthreads();
+  GDN_STAMP(3);
 
   // ---- epilogue: row-major 16-byte pieces, operands from registers ----------------------------
 #pragma unroll
@@ -294,6 +309,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  GDN_STAMP(4);
 }
 
 template <int NC, int WM, int WN, int MODE, int PRO>

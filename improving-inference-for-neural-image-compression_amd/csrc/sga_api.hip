@@ -168,12 +168,13 @@ namespace {
 
 // Estimated fraction of the MFMA peak a launch of `n` equal workgroups of `bm`-row tiles reaches: resident
 // workgroups per CU (3 / 2 / 1 for 64 / 128 / 256 rows), the rate a CU sustains with that many (measured at
-// cfg 2: 64-row 2/CU 0.79-0.80, 128-row 2/CU 0.80, 256-row 0.79-0.82; one 4-wave workgroup alone 0.55-0.62),
+// cfg 2: 64-row 2/CU 0.79-0.80, 128-row 2/CU 0.80, 256-row 8-wave 0.86-0.90 with the LDS-DMA loop; one 4-wave workgroup
+// alone 0.55-0.62),
 // and the quantisation of n into rounds of 256 x resident.  Kodak, 3 images: gs2.bwd as 576 128-row tiles
 // measured 0.51 (estimate 0.45), as 1152 64-row tiles the estimate is 0.63.
 double grid_efficiency(int bm, long long n) {
   const int per_cu = bm == 64 ? 3 : (bm == 128 ? 2 : 1);
-  static const double R64[4] = {0, 0.55, 0.80, 0.84}, R128[3] = {0, 0.62, 0.80}, R256[2] = {0, 0.82};
+  static const double R64[4] = {0, 0.55, 0.80, 0.84}, R128[3] = {0, 0.62, 0.80}, R256[2] = {0, 0.88};
   long long c = (n + 255) / 256;
   if (c > per_cu) c = per_cu;
   if (c < 1) c = 1;
@@ -214,7 +215,8 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   // Tecnick image: 704 128-row tiles = 1.4 rounds of 512), and 128-row launches in general (176 tiles x 3 =
   // 528 workgroups is two rounds) -- the split is the multiple S of the grid with the best estimated
   // efficiency, each extra slab priced at 3.5 %.
-  const bool search = h->plan_tiles && ((a.bm == 64 && big) || (a.bm == 128 && blocks > 128 && (bn == 192 || bn == 256)));
+  const bool search = h->plan_tiles && ((a.bm == 64 && big) || (a.bm == 128 && blocks > 128 && (bn == 192 || bn == 256)) ||
+                                        (a.bm == 256 && a.nphase == 1 && blocks > 128 && blocks != 256 && h->bm256_split));
   if (search) {
     int best = 1;
     (void)best_split(a.bm, blocks, &best);
@@ -297,6 +299,10 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
         const double e256 = grid_efficiency(256, n256) * (with_post ? 1.17 : 1.0);
         if (e256 >= e) { e = e256; bm = 256; }
       }
+      if (h->bm256_split && a.nphase == 1 && n256 > 128) {      // 256-row tiles split along K (no IGDN post-phase then)
+        const double e256s = best_split(256, n256, nullptr);
+        if (e256s > e) { e = e256s; bm = 256; }
+      }
       if (h->bm64_max > 0) {
         const double e64 = n64 > 256 ? best_split(64, n64, nullptr) : grid_efficiency(64, n64);
         if (e64 > e * 1.03) { e = e64; bm = 64; }
@@ -312,7 +318,9 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     const long long n128 = (long long)a.nphase * cdiv(rows, 128) * a.ntiles_n;
     const long long n256 = (long long)a.nphase * cdiv(rows, 256) * a.ntiles_n;
     const double bonus = 1.04;      // the LDS-DMA loop against the register-staged 128-row one
-    if (n128 >= 512 && grid_efficiency(256, n256) * bonus >= best_split(128, n128, nullptr)) {
+    double e256 = grid_efficiency(256, n256);
+    if (h->bm256_split && a.nphase == 1) e256 = std::max(e256, best_split(256, n256, nullptr));
+    if (n128 >= 512 && e256 * bonus >= best_split(128, n128, nullptr)) {
       a.bm = 256;
       a.tiles_per_phase = (int)cdiv(rows, 256);
     }
@@ -690,6 +698,23 @@ int gdn_launch(sga_handle* h, GdnArgs& g, hipStream_t st) {
     HIPCHK(h, hipEventCreate(&r.b));
     HIPCHK(h, hipEventRecord(r.a, st));
   }
+#ifdef SGA_CLOCK_PROBE
+  g.clk = nullptr;
+  if (h->clk_mode == 2 && h->clk_slots.size() < 40) {
+    hipStreamCaptureStatus ccs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &ccs);
+    const long long grid = (g.M + gdn_tile_rows(g.C, g.M, g.pro) - 1) / gdn_tile_rows(g.C, g.M, g.pro);
+    if (ccs == hipStreamCaptureStatusActive && grid * 8 <= 6 * 16384) {
+      g.clk = h->clk_probe + h->clk_slots.size() * (size_t)(6 * 16384);
+      sga_handle::ClkSlot cs;
+      char kn[64];
+      gdn_kernel_name(g, kn, sizeof(kn));
+      snprintf(cs.name, sizeof(cs.name), "gdn:%s %s", h->cur_tag, kn);
+      cs.grid = (int)grid;
+      h->clk_slots.push_back(cs);
+    }
+  }
+#endif
   HIPCHK(h, launch_gdn_tile(g, st));
   if (h->profiling) {
     HIPCHK(h, hipEventRecord(r.b, st));
@@ -1342,6 +1367,15 @@ int sga_destroy(sga_handle* h) {
     std::vector<unsigned long long> t(6 * 16384);
     for (size_t s = 0; s < h->clk_slots.size(); ++s) {
       if (hipMemcpy(t.data(), h->clk_probe + s * (size_t)(6 * 16384), t.size() * sizeof(t[0]), hipMemcpyDeviceToHost) != hipSuccess) break;
+      if (strncmp(h->clk_slots[s].name, "gdn:", 4) == 0) {      // raw [grid][8] u64 wall-clock stamps (gdn_fused.hip)
+        if (const char* dir = getenv("SGA_CLOCK_PROBE_DUMP")) {
+          char fn[512];
+          snprintf(fn, sizeof(fn), "%s/gdn_slot_%02zu.bin", dir, s);
+          if (FILE* f = fopen(fn, "wb")) { fwrite(t.data(), sizeof(t[0]), 8 * (size_t)h->clk_slots[s].grid, f); fclose(f); }
+        }
+        fprintf(stderr, "clock_probe(graph) slot %zu %s grid %d\n", s, h->clk_slots[s].name, h->clk_slots[s].grid);
+        continue;
+      }
       double c = 0, w = 0, wmin = 1e30, wmax = 0;
       for (int i = 0; i < h->clk_slots[s].grid; ++i) {
         c += (double)t[6 * i]; w += (double)t[6 * i + 1];

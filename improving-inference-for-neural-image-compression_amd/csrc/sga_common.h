@@ -133,6 +133,10 @@ struct GdnArgs {
   float* s_out_p;          // forward IGDN: sqrt(n) (or null)
   float* u_out;            // forward: T written back (needed when T was assembled here), or null
   double flops;            // algorithmic flops (profiling only)
+#ifdef SGA_CLOCK_PROBE
+  unsigned long long* clk; // measurement build: per workgroup 8 x u64 = wall clock (100 MHz) at entry, after the prologue,
+                           //   after the fill, after the contraction, at exit, hw_id | xcc_id << 32
+#endif
 };
 int launch_gdn_tile(const GdnArgs& a, hipStream_t stream);
 int gdn_tile_rows(int C, long long M, int pro);

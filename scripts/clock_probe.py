@@ -29,3 +29,26 @@ for f in sorted(glob.glob(os.path.join(dump, "clk_slot_*.bin"))):
           f"  blocks[:n/2] {wall[:h].mean():7.1f}  blocks[n/2:] {wall[h:].mean():7.1f}  per XCC "
           + " ".join(f"{wall[xcc == k].mean():.0f}" for k in range(8) if (xcc == k).any())
           + f"  | prologue mean {pro.mean():.1f} max {pro.max():.1f}  after-K-loop mean {epi.mean():.1f} max {epi.max():.1f}  launch span {span:.1f}")
+
+print("GDN tile kernel phases (wall clock per workgroup, us): prologue | fill (loads -> operand in LDS) | contraction | epilogue (stores)")
+for f in sorted(glob.glob(os.path.join(dump, "gdn_slot_*.bin"))):
+    t = np.fromfile(f, dtype=np.uint64).reshape(-1, 8)
+    st = t[:, :5].astype(float) / 100.0
+    st -= st[:, 0].min()
+    d = np.diff(st, axis=1)
+    ids = t[:, 5]; hw = (ids & np.uint64(0xffffffff)).astype(np.int64); xcc = (ids >> np.uint64(32)).astype(np.int64) & 0xF
+    cu = xcc * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xF)
+    span = st[:, 4].max()
+    # per CU: time with >= 1 / 2 workgroups inside the contraction phase
+    one = two = 0.0; ncu = 0
+    for c in np.unique(cu):
+        sel = cu == c
+        ev = sorted([(a, 1) for a in st[sel, 2]] + [(b, -1) for b in st[sel, 3]])
+        k = 0; last = 0.0
+        for x, dlt in ev:
+            if k >= 1: one += x - last
+            if k >= 2: two += x - last
+            k += dlt; last = x
+        ncu += 1
+    print(f"{os.path.basename(f)} n={len(t):5d} CUs {ncu}  span {span:7.1f}  phases mean {d[:,0].mean():6.1f} | {d[:,1].mean():6.1f} | {d[:,2].mean():6.1f} | {d[:,3].mean():6.1f}"
+          f"  (max {d[:,0].max():.1f} {d[:,1].max():.1f} {d[:,2].max():.1f} {d[:,3].max():.1f})  per CU: in contraction {one/ncu:6.1f} us ({100*one/ncu/span:.0f} % of span), two at once {two/ncu:6.1f} us")
