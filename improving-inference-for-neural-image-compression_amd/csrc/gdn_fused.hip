@@ -56,8 +56,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
   const int wm = wid / WN, wn = wid % WN;
   const int chunk = tid & 7, lrow = tid >> 3;
   const int half = lane >> 5, col = lane & 31, koff = half * 4;
-  const long long m0 = (long long)blockIdx.x * BM;
   const float* __restrict__ gw = a.w;
+  const long long m0 = (long long)blockIdx.x * BM;
 #ifdef SGA_CLOCK_PROBE
 #define GDN_STAMP(k) do { if (a.clk && tid == 0) a.clk[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
   if (a.clk && tid == 0) {
@@ -135,8 +135,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
       }
     }
     zero_acc();
-    f32x4 ra[PA];
-    auto load_a = [&](int step) {
+    // All three K-steps' operands are requested up front (registers are free here: the fill's streams and the
+    // epilogue registers are not live yet).  Step by step -- load, LDS, barrier, multiply -- the prologue was three
+    // dependent round trips to L2: 11.1 us per workgroup for 3.9 us of MFMA work (in-kernel stamps,
+    // profiles/r02_clock_probe.txt).
+    f32x4 ra[3][PA], rbs[3][PB];
+#pragma unroll
+    for (int step = 0; step < 3; ++step) {
       // one K-step = kernel rows (2*step, 2*step+1), 16 floats each (5 taps x 3 channels + 1 of slack
       // that meets a zero weight); row 5 does not exist: its weights are zero, re-read row 4
       int ky = 2 * step + (chunk >> 2);
@@ -146,21 +151,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
         const bool okp = a_off[p] >= 0;
         const float* src = a.pad + (size_t)(okp ? a_off[p] : 0) + (size_t)ky * a.Wp * 3 + (chunk & 3) * 4;
         const f32x2 lo = ld2(src), hi = ld2(src + 2);
-        ra[p] = okp ? f32x4{lo.x, lo.y, hi.x, hi.y} : f32x4{0.f, 0.f, 0.f, 0.f};
+        ra[step][p] = okp ? f32x4{lo.x, lo.y, hi.x, hi.y} : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    };
-    load_a(0);
-    load_b(a.wc, 32, 0);
-#pragma unroll 1
+#pragma unroll
+      for (int p = 0; p < PB; ++p) rbs[step][p] = ld4(a.wc + (size_t)step * C * 32 + (size_t)(p * RPP + lrow) * 32 + chunk * 4);
+    }
+#pragma unroll
     for (int step = 0; step < 3; ++step) {
 #pragma unroll
-      for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(&As[(p * RPP + lrow) * LDK + chunk * 4]) = ra[p];
-      store_b();
+      for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(&As[(p * RPP + lrow) * LDK + chunk * 4]) = ra[step][p];
+#pragma unroll
+      for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(&Bs[(p * RPP + lrow) * LDK + chunk * 4]) = rbs[step][p];
       __syncthreads();
-      if (step + 1 < 3) {
-        load_a(step + 1);
-        load_b(a.wc + (size_t)(step + 1) * C * 32, 32, 0);
-      }
       mfma_step(As, LDK, 0);
       __syncthreads();
     }
