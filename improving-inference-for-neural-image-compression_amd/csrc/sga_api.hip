@@ -130,6 +130,7 @@ struct sga_handle {
 
   // ---- cached step graph ----
   hipGraphExec_t graph_exec = nullptr;
+  int side_target = 0;             // experiment: split-K target (workgroups per launch) of the hyper branch (SGA_SIDE_TARGET)
   bool side_last = true;           // graph capture: create the hyper branch's nodes after the main chain's (SGA_SIDE_LAST=0: before)
   int graph_B = 0, graph_H = 0, graph_W = 0, graph_relax = 0;
   hipGraphExec_t bb_graph[2] = {nullptr, nullptr};   // one iteration of bits-back stage 1 / stage 2
@@ -208,6 +209,7 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   const int tiles = a.tiles_per_phase * a.ntiles_n;
   const int blocks = a.nphase * tiles;
   int target = a.bm == 256 ? 256 : 512;      // ~512 workgroups of (nearly) equal K length (tuned at cfg 2); 256-row: one per CU
+  if (h->cur_part == &h->partB && h->side_target > 0) target = h->side_target;   // hyper branch (second stream)
   const int bn = a.Npad / a.ntiles_n;
   const bool big = blocks > 256 || (blocks == 256 && a.nphase == 1 && !h->split256);
   // Where the cfg-2 rule does not reach -- grids of more than 256 blocks that still quantise badly into
@@ -1341,6 +1343,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   if (env) h->fork_at = atoi(env);
   env = getenv("SGA_SIDE_LAST");
   if (env) h->side_last = env[0] == '1';
+  env = getenv("SGA_SIDE_TARGET");
+  if (env) h->side_target = atoi(env);
   env = getenv("SGA_FUSED_GDN");
   h->fused_gdn = !(env && env[0] == '0');
   env = getenv("SGA_FUSED_POST");
