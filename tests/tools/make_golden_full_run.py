@@ -11,6 +11,9 @@ decision, after which the two runs are different samples of the same stochastic 
 criterion is statistical: this script also records the oracle's own seed-to-seed spread.
 
     python tests/tools/make_golden_full_run.py            # ~8 min on 4 cores (the small set)
+
+NSEEDS=<n> extends a set to seeds 0..n-1: runs already in the output file are kept (a run is a pure function
+of its seed), only the missing seeds are computed.
 """
 import json
 import os
@@ -28,6 +31,8 @@ CFGS = {
 }
 NAME = os.environ.get("GOLDEN", "")
 CFG = CFGS[NAME]
+if os.environ.get("NSEEDS"):
+    CFG["seeds"] = list(range(int(os.environ["NSEEDS"])))
 OUT = os.path.join(ROOT, "tests", "golden", "full_run_oracle%s.json" % ("_" + NAME if NAME else ""))
 
 
@@ -56,8 +61,18 @@ def one_seed(seed):
 def main():
     import numpy as np
     nproc = int(os.environ.get("NPROC", 3))
+    have = {}
+    if os.environ.get("NSEEDS") and os.path.exists(OUT):
+        with open(OUT) as f:
+            old = json.load(f)
+        assert {k: v for k, v in old["config"].items() if k != "seeds"} == {k: v for k, v in CFG.items() if k != "seeds"}
+        have = {r["seed"]: r for r in old["runs"]}
+    todo = [s for s in CFG["seeds"] if s not in have]
     with Pool(nproc) as pool:
-        runs = pool.map(one_seed, CFG["seeds"])
+        for r in pool.imap_unordered(one_seed, todo):
+            have[r["seed"]] = r
+            print("seed", r["seed"], "%.0f s" % r["seconds"], flush=True)
+    runs = [have[s] for s in CFG["seeds"]]
     bpp = np.array([r["est_bpp"] for r in runs])     # [seed, image]
     psnr = np.array([r["psnr"] for r in runs])
     out = dict(config=CFG, runs=runs,
