@@ -16,6 +16,9 @@ the GPU box.  Fixtures are data (inputs + the reference's outputs); no reference
   `lower_bound` / `upper_bound` are executed unmodified against a small numpy-backed stand-in for the
   TensorFlow names they use (matmul, softplus, tanh, sigmoid, transpose, reshape, logical_or, cast).
 
+* nn_models.py is imported as it stands against recording stand-ins for `tf.keras.layers.Layer`,
+  `tfc.SignalConv2D` and `tfc.GDN`: the layer table of the four transforms -> architecture_reference.json.
+
     python scripts/make_golden_from_reference.py
 """
 import json
@@ -231,10 +234,99 @@ def prior_fixtures():
     assert np.allclose(fd, out["pdf"], rtol=1e-6, atol=1e-10), np.abs(fd - out["pdf"]).max()
 
 
+def architecture_fixture():
+    """nn_models.py imported as it stands, with `tensorflow.compat.v1` and `tensorflow_compression` replaced by
+    recording stand-ins: `tf.keras.layers.Layer` is an empty base class, `tfc.SignalConv2D` / `tfc.GDN` store
+    their constructor arguments.  The four transforms are constructed exactly as sga.py:70-73 (and bb_sga.py:69
+    for the bits-back hyper-analysis) construct them, `build()` runs, and every layer's arguments are written
+    out: the layer table (order, filters, kernel support, corr, strides, padding, bias, activation) is then
+    the reference's own, not a reading of it.  Pins the ARCHITECTURE; what `SignalConv2D` / `GDN` compute for
+    these arguments remains tfc 1.3's (un-vendored)."""
+    import importlib.util
+    import types
+
+    class Layer:
+        def __init__(self, *a, **k):
+            pass
+
+        def build(self, input_shape):
+            pass
+
+    def relu(x):
+        raise RuntimeError("not executed")
+
+    class Rec:
+        def __init__(self, *args, **kwargs):
+            self.args, self.kwargs = args, kwargs
+
+    class SignalConv2D(Rec):
+        pass
+
+    class GDN(Rec):
+        pass
+
+    tf1 = types.ModuleType("tensorflow.compat.v1")
+    tf1.keras = types.SimpleNamespace(layers=types.SimpleNamespace(Layer=Layer))
+    tf1.nn = types.SimpleNamespace(relu=relu)
+    tfmod, compat = types.ModuleType("tensorflow"), types.ModuleType("tensorflow.compat")
+    tfmod.compat, compat.v1 = compat, tf1
+    tfc = types.ModuleType("tensorflow_compression")
+    tfc.SignalConv2D, tfc.GDN = SignalConv2D, GDN
+    stubs = {"tensorflow": tfmod, "tensorflow.compat": compat, "tensorflow.compat.v1": tf1,
+             "tensorflow_compression": tfc}
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    try:
+        spec = importlib.util.spec_from_file_location("_reference_nn_models", os.path.join(REF, "nn_models.py"))
+        nn = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(nn)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+    def describe(t):
+        t.build(None)
+        rows = []
+        for lay in t._layers:
+            assert isinstance(lay, SignalConv2D)
+            kw = dict(lay.kwargs)
+            act = kw.pop("activation")
+            if isinstance(act, GDN):
+                assert not act.args and set(act.kwargs) <= {"name", "inverse"}, act.kwargs
+                a = {"kind": "gdn", "inverse": bool(act.kwargs.get("inverse", False)), "name": act.kwargs["name"]}
+            elif act is relu:
+                a = {"kind": "relu"}
+            else:
+                assert act is None
+                a = {"kind": "none"}
+            rows.append({"filters": int(lay.args[0]), "kernel_support": [int(v) for v in lay.args[1]],
+                         "activation": a, **kw})
+        return rows
+
+    out = {}
+    for C in (192, 256, 64):
+        out[str(C)] = {
+            "analysis": describe(nn.AnalysisTransform(C)),                                           # sga.py:70
+            "synthesis": describe(nn.SynthesisTransform(C)),                                         # sga.py:71
+            "hyper_analysis": describe(nn.HyperAnalysisTransform(C)),                                # sga.py:72
+            "hyper_synthesis": describe(nn.MBT2018HyperSynthesisTransform(C, num_output_filters=2 * C)),  # sga.py:73
+            "hyper_analysis_bb": describe(nn.HyperAnalysisTransform(C, num_output_filters=2 * C)),   # bb_sga.py:69
+        }
+    with open(os.path.join(OUT, "architecture_reference.json"), "w") as f:
+        json.dump({"source": "nn_models.py executed with recording stand-ins for tf.keras.layers.Layer, "
+                             "tfc.SignalConv2D, tfc.GDN (scripts/make_golden_from_reference.py); "
+                             "constructed as at sga.py:70-73, bb_sga.py:69",
+                   "num_filters": out}, f, indent=1)
+
+
 def main():
     sys.path.insert(0, REF)
     os.makedirs(OUT, exist_ok=True)
     utils_fixtures()
+    architecture_fixture()
     prior_fixtures()
     import adam as ref_adam          # /root/reference/adam.py
     import configs as ref_configs    # /root/reference/configs.py

@@ -279,3 +279,89 @@ def test_msssim_oracle_properties():
     assert torch.allclose(a, ssim_multiscale(y1, x, 255.0))
     with pytest.raises(ValueError):
         ssim_multiscale(x[:, :100], x[:, :100], 255.0)
+
+
+# ---- architecture: nn_models.py executed against recording stand-ins (tests/golden/architecture_reference.json)
+
+def _trace_oracle_transform(o, fn, x):
+    """The sequence of layer operations one oracle transform performs, recorded by wrapping its primitives."""
+    import oracle.sga_oracle as mod
+    ops = []
+    saved = {n: getattr(o, n) for n in ("_conv_down", "_conv_up", "_conv_same_true", "_gdn")}
+    relu0 = mod.F.relu
+
+    def wrap(name):
+        def f(*a, **k):
+            ops.append((name, a[1:], k))
+            return saved[name](*a, **k)
+        return f
+
+    def relu(t, *a, **k):
+        ops.append(("relu", (), {}))
+        return relu0(t, *a, **k)
+
+    for n in saved:
+        setattr(o, n, wrap(n))
+    mod.F.relu = relu
+    try:
+        with torch.no_grad():
+            fn(torch.as_tensor(x))
+    finally:
+        mod.F.relu = relu0
+        for n in saved:
+            delattr(o, n)
+    return ops
+
+
+@pytest.mark.parametrize("C", [64, 192])
+def test_architecture_matches_reference_executed_layer_table(C):
+    """Layer order, filters, kernel support, corr / stride direction, bias flags and activations of the four
+    transforms, as nn_models.py itself declares them (sga.py:70-73, bb_sga.py:69), against (a) the operations
+    the oracle performs and (b) the tensor layout the product takes across the C ABI (weights.layer_shapes)."""
+    from sga_amd.weights import layer_shapes
+    with open(os.path.join(GOLDEN, "architecture_reference.json")) as f:
+        ref = json.load(f)["num_filters"][str(C)]
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    o = SGAOracle(w)
+    shapes = layer_shapes(C)
+    x = np.random.RandomState(0).rand(1, 32, 32, 3).astype(np.float32)
+    y, z = o.encode(x)
+    cases = [("analysis", "ga", o.analysis, x, 3), ("synthesis", "gs", o.synthesis, y.numpy(), C),
+             ("hyper_analysis", "ha", o.hyper_analysis, y.numpy(), C),
+             ("hyper_synthesis", "hs", o.hyper_synthesis, z.numpy(), C)]
+    for tname, pre, fn, inp, cin in cases:
+        expect = []
+        for i, lay in enumerate(ref[tname]):
+            assert lay["name"] == f"layer_{i}" and lay["padding"] == "same_zeros"
+            kh, kw = lay["kernel_support"]
+            # (b) the effective-weight layout: HWIO kernel, bias present iff use_bias
+            assert shapes[f"{pre}.k{i}"] == (kh, kw, cin, lay["filters"]), (tname, i)
+            assert (f"{pre}.b{i}" in shapes) == lay["use_bias"], (tname, i)
+            bias = f"{pre}.b{i}" if lay["use_bias"] else None
+            # (a) which primitive the oracle must use for these arguments
+            if lay["corr"]:
+                assert "strides_up" not in lay
+                expect.append(("_conv_down", (f"{pre}.k{i}", bias, lay["strides_down"]), {}))
+            elif lay["strides_up"] == 2:
+                assert "strides_down" not in lay and (kh, kw) == (5, 5)
+                expect.append(("_conv_up", (f"{pre}.k{i}", bias), {}))
+            else:
+                assert lay["strides_up"] == 1 and (kh, kw) == (3, 3)
+                expect.append(("_conv_same_true", (f"{pre}.k{i}", bias), {}))
+            act = lay["activation"]
+            if act["kind"] == "gdn":
+                assert act["name"] == ("igdn_%d" if act["inverse"] else "gdn_%d") % i
+                assert shapes[f"{pre}.gamma{i}"] == (lay["filters"], lay["filters"])
+                expect.append(("_gdn", (pre, i, act["inverse"]), {}))
+            elif act["kind"] == "relu":
+                expect.append(("relu", (), {}))
+            cin = lay["filters"]
+        assert _trace_oracle_transform(o, fn, inp) == expect, tname
+    # the bits-back hyper-analysis emits (z_mean | z_logvar): bb_sga.py:69
+    assert [l["filters"] for l in ref["hyper_analysis_bb"]] == [C, C, 2 * C]
+    assert layer_shapes(C, bb=True)["ha.k2"] == (5, 5, C, 2 * C)
+    assert [{k: v for k, v in l.items() if k != "filters"} for l in ref["hyper_analysis_bb"]] == \
+           [{k: v for k, v in l.items() if k != "filters"} for l in ref["hyper_analysis"]]
+    # the importer reads `kernel` (not `kernel_rdft`) exactly where nn_models.py passes kernel_parameterizer=None
+    assert all("kernel_parameterizer" in l and l["kernel_parameterizer"] is None for l in ref["hyper_synthesis"])
+    assert not any("kernel_parameterizer" in l for t in ("analysis", "synthesis", "hyper_analysis") for l in ref[t])
