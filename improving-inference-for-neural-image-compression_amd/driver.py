@@ -269,6 +269,8 @@ def parse_args(argv):
     p = argparse.ArgumentParser(description="SGA iterative inference on MI355X (sga.py drop-in)")
     p.add_argument("--verbose", "-V", action="store_true")
     p.add_argument("--num_filters", type=int, default=-1)
+    p.add_argument("--num_hfilters", type=int, default=-1,
+                   help="accepted like the reference's parser does; only its training run names use it (utils.py:65)")
     p.add_argument("--checkpoint_dir", default="./checkpoints")
     p.add_argument("--seed", type=int, default=0)
     sub = p.add_subparsers(dest="command")

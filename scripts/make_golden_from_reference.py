@@ -322,11 +322,49 @@ def architecture_fixture():
                    "num_filters": out}, f, indent=1)
 
 
+def cli_fixture():
+    """tf_boilerplate.py:91-204 (`parse_args`), executed unmodified with `absl.flags.argparse_flags` bound to
+    argparse (argparse_flags.ArgumentParser is an argparse.ArgumentParser that also knows absl's own flags):
+    the namespaces the reference's command line produces for a set of `compress` invocations."""
+    import argparse
+    import types
+    absl = types.ModuleType("absl")
+    flags = types.ModuleType("absl.flags")
+    af = types.ModuleType("absl.flags.argparse_flags")
+    af.ArgumentParser = argparse.ArgumentParser
+    absl.flags, flags.argparse_flags = flags, af
+    stubs = {"absl": absl, "absl.flags": flags, "absl.flags.argparse_flags": af}
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    try:
+        ns = {"sys": sys}
+        _exec_reference_defs("tf_boilerplate.py", ["parse_args"], ns)
+        cases = [
+            ["--num_filters", "192", "compress", "mbt2018-num_filters=192-lmbda=0.01", "kodak.npy"],
+            ["--verbose", "--num_filters", "256", "--checkpoint_dir", "/ckpt", "compress", "--lambda", "0.08",
+             "--annealing_rate", "0.002", "--t0", "100", "--sga_its", "500", "--results_dir", "",
+             "mbt2018-num_filters=256-lmbda=0.08", "tecnick.npy", "out.tfci"],
+            ["-V", "--num_filters", "128", "--num_hfilters", "64", "compress", "run-lmbda=0.04-x", "in.png"],
+        ]
+        out = [{"argv": argv, "namespace": vars(ns["parse_args"](["prog"] + argv))} for argv in cases]
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    with open(os.path.join(OUT, "cli_reference.json"), "w") as f:
+        json.dump({"source": "tf_boilerplate.py parse_args executed with argparse_flags.ArgumentParser = "
+                             "argparse.ArgumentParser (scripts/make_golden_from_reference.py)", "cases": out},
+                  f, indent=1)
+
+
 def main():
     sys.path.insert(0, REF)
     os.makedirs(OUT, exist_ok=True)
     utils_fixtures()
     architecture_fixture()
+    cli_fixture()
     prior_fixtures()
     import adam as ref_adam          # /root/reference/adam.py
     import configs as ref_configs    # /root/reference/configs.py

@@ -2,6 +2,7 @@
 header declares, the product path refuses to run without the HIP extension / a GPU, the host
 logic mirrors the reference's (batching, file naming, lambda parsing), and the N>1 sharding +
 gather path works under gloo with world_size 2."""
+import json
 import os
 import re
 import sys
@@ -128,6 +129,19 @@ def test_cli_flags_match_reference():
     a = driver.parse_args(["--num_filters", "192", "compress", "run-lmbda=0.04-x", "in.npy"])
     assert (a.lmbda, a.sga_its, a.annealing_rate, a.t0, a.results_dir) == (-1, 2000, 1e-3, 700, "./results")
     assert a.command == "compress" and a.runname == "run-lmbda=0.04-x" and a.input_file == "in.npy"
+
+
+def test_cli_namespaces_match_reference_executed_parser():
+    """tests/golden/cli_reference.json: tf_boilerplate.py's `parse_args` executed on these command lines
+    (scripts/make_golden_from_reference.py).  The host's parser must yield the same value for every name the
+    reference's namespace has (it may have more: --method, --seed, ...)."""
+    with open(os.path.join(ROOT, "tests", "golden", "cli_reference.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 3
+    for c in cases:
+        got = vars(driver.parse_args(c["argv"]))
+        for k, v in c["namespace"].items():
+            assert k in got and got[k] == v and type(got[k]) is type(v), (c["argv"], k, got.get(k), v)
 
 
 def test_load_images_npy_and_png(tmp_path):
