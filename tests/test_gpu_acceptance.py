@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL_BPP, TOL_PSNR = 1e-3, 0.01          # north_star tolerance
 
 
-# the small set (C = 64, 4 x 64^2, 32 seeds) and one at the north star's width (C = 192, 2 x 128^2, 16 seeds)
+# the small set (C = 64, 4 x 64^2, 32 seeds) and one at the north star's width (C = 192, 2 x 128^2, 64 seeds)
 @pytest.mark.parametrize("golden", ["full_run_oracle.json", "full_run_oracle_c192.json"])
 def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir, golden):
     from sga_amd.codec import SGACodec, metrics_to_dict

@@ -24,10 +24,10 @@ from multiprocessing import Pool
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 # two sets: the small one (C = 64, 4 x 64^2, 32 seeds) and one at the north star's width (C = 192, 2 x 128^2,
-# 16 seeds; ~6 min per seed on one core):  GOLDEN=c192 NPROC=7 python tests/tools/make_golden_full_run.py
+# 64 seeds; ~6 min per seed on one core):  GOLDEN=c192 NPROC=7 python tests/tools/make_golden_full_run.py
 CFGS = {
     "": dict(C=64, B=4, H=64, W=64, its=2000, lmbda=0.01, x_seed=6, weight_seed=0, seeds=list(range(32))),
-    "c192": dict(C=192, B=2, H=128, W=128, its=2000, lmbda=0.01, x_seed=7, weight_seed=0, seeds=list(range(16))),
+    "c192": dict(C=192, B=2, H=128, W=128, its=2000, lmbda=0.01, x_seed=7, weight_seed=0, seeds=list(range(64))),
 }
 NAME = os.environ.get("GOLDEN", "")
 CFG = CFGS[NAME]
