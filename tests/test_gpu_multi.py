@@ -127,3 +127,21 @@ def test_bench_two_ranks_and_rccl_world1_equal_plain_bench(tmp_path):
     assert two["n_gpus"] == 2 and two["config"]["images_per_step"] == 4 and m2.shape == (4, 7)
     assert np.array_equal(m2[:2], m1, equal_nan=True)      # rank 0's images: same inputs, same result
     assert two["scaling"] == "weak" and two["value"] > 0
+
+
+def test_bench_launch_line_at_world_size_8(tmp_path):
+    """The driver's N = 8 line (`python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`) with all
+    eight ranks on the one GPU (gloo): rendezvous, the [8 x B, 7] gather, the max-over-ranks timing, and rank r's rows
+    equal what a single process computes for rank r's inputs (x is seeded with 1000 + rank)."""
+    port = 29800 + os.getpid() % 90
+    eight = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                  "--master-addr", "127.0.0.1", "--master-port", str(port), *BENCH, "--gpus", "8",
+                  "--dump-metrics", str(tmp_path / "m8.npy")],
+                 dict(SGA_BENCH_BACKEND="gloo", SGA_BENCH_SHARE_DEVICE="1"))
+    m8 = np.load(tmp_path / "m8.npy")
+    assert eight["n_gpus"] == 8 and eight["config"]["images_per_step"] == 16 and m8.shape == (16, 7)
+    assert eight["scaling"] == "weak" and eight["value"] > 0 and np.isfinite(m8[:, [1, 4]]).all()
+    plain = _run([sys.executable, *BENCH, "--gpus", "1", "--dump-metrics", str(tmp_path / "m1.npy")], {})
+    assert plain["n_gpus"] == 1
+    assert np.array_equal(m8[:2], np.load(tmp_path / "m1.npy"), equal_nan=True)
+    assert not np.array_equal(m8[2:4], m8[:2])          # other ranks work on other images
