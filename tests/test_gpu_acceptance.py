@@ -25,8 +25,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL_BPP, TOL_PSNR = 1e-3, 0.01          # north_star tolerance
 
 
-# the small set (C = 64, 4 x 64^2, 32 seeds) and one at the north star's width (C = 192, 2 x 128^2, 64 seeds)
-@pytest.mark.parametrize("golden", ["full_run_oracle.json", "full_run_oracle_c192.json"])
+# the small set (C = 64, 4 x 64^2, 32 seeds), one at the north star's width (C = 192, 2 x 128^2, 64 seeds), and cfg 5:
+# the complete two-stage bits-back run of bb_sga.py:199-276 (C = 64, 2 x 64^2, 2000 + 2000 iterations, 32 seeds)
+@pytest.mark.parametrize("golden", ["full_run_oracle.json", "full_run_oracle_c192.json", "full_run_oracle_bb.json"])
 def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir, golden):
     from sga_amd.codec import SGACodec, metrics_to_dict
     with open(os.path.join(ROOT, "tests", "golden", golden)) as f:
@@ -34,12 +35,18 @@ def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir,
     cfg = gold["config"]
     C, B, H, W = cfg["C"], cfg["B"], cfg["H"], cfg["W"]
     x = np.random.RandomState(cfg["x_seed"]).rand(B, H, W, 3).astype(np.float32)
-    w = sga_amd.make_synthetic_weights(C, seed=cfg["weight_seed"])
-    codec = SGACodec(w, C, B, H, W, precision="f32")
-    d_bpp, d_psnr, hip_bpp, hip_psnr = [], [], [], []
+    bb = bool(cfg.get("bb"))
+    w = sga_amd.make_synthetic_weights(C, seed=cfg["weight_seed"], bb=bb)
+    codec = SGACodec(w, C, B, H, W, precision="f32", bits_back=bb)
+    d_bpp, d_psnr, hip_bpp, hip_psnr, d_back = [], [], [], [], []
     for run in gold["runs"]:
-        _, _, met, _ = codec.run(x, cfg["lmbda"], its=cfg["its"], seed=run["seed"])
+        if bb:
+            _, _, met, _, _ = codec.bb_run(x, cfg["lmbda"], its=cfg["its"], r_its=cfg["r_its"], seed=run["seed"])
+        else:
+            _, _, met, _ = codec.run(x, cfg["lmbda"], its=cfg["its"], seed=run["seed"])
         m = metrics_to_dict(met)
+        if bb:
+            d_back.append(m["est_bpp_back"].astype(np.float64) - np.array(run["est_bpp_back"]))
         d_bpp.append(m["est_bpp"].astype(np.float64) - np.array(run["est_bpp"]))
         d_psnr.append(m["psnr"].astype(np.float64) - np.array(run["psnr"]))
         hip_bpp.append(m["est_bpp"].astype(np.float64)); hip_psnr.append(m["psnr"].astype(np.float64))
@@ -58,12 +65,18 @@ def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir,
                oracle_seed_std_bpp=spread["est_bpp_std_per_image"],
                hip_seed_std_psnr=np.array(hip_psnr).std(0, ddof=1).tolist(),
                oracle_seed_std_psnr=spread["psnr_std_per_image"])
+    if bb:      # the bits-back refund (bb_sga.py:181 `est_bpp_back`): the net rate is est_bpp - est_bpp_back
+        d_back = np.array(d_back)
+        rep.update(mean_d_bpp_back=float(d_back.mean()), sem_d_bpp_back=float(d_back.std(ddof=1) / np.sqrt(n)),
+                   max_abs_d_bpp_back=float(np.abs(d_back).max()))
     with open(os.path.join(gpu_out_dir, golden.replace("full_run_oracle", "acceptance_full_run")), "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps(rep))
     # the north-star tolerance, on the means (standard errors stated in the report: ~3e-4 bpp, ~1e-3 dB)
     assert abs(rep["mean_d_bpp"]) <= TOL_BPP, rep
     assert abs(rep["mean_d_psnr"]) <= TOL_PSNR, rep
+    if bb:
+        assert abs(rep["mean_d_bpp_back"]) <= TOL_BPP, rep
     # per image (mean over the seeds): no systematic offset of any image beyond the tolerance
     assert np.abs(d_bpp.mean(0)).max() <= TOL_BPP, rep
     assert np.abs(d_psnr.mean(0)).max() <= TOL_PSNR, rep

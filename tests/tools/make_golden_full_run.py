@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 # 64 seeds; ~6 min per seed on one core):  GOLDEN=c192 NPROC=7 python tests/tools/make_golden_full_run.py
 CFGS = {
     "": dict(C=64, B=4, H=64, W=64, its=2000, lmbda=0.01, x_seed=6, weight_seed=0, seeds=list(range(32))),
+    # cfg 5 (bb_sga.py:199-276): both stages, 2000 + 2000 iterations, bits-back weights (hyper-analysis emits mean | logvar)
+    "bb": dict(C=64, B=2, H=64, W=64, its=2000, r_its=2000, lmbda=0.01, x_seed=8, weight_seed=0, bb=True,
+               seeds=list(range(32))),
     "c192": dict(C=192, B=2, H=128, W=128, its=2000, lmbda=0.01, x_seed=7, weight_seed=0, seeds=list(range(64))),
 }
 NAME = os.environ.get("GOLDEN", "")
@@ -47,15 +50,21 @@ def one_seed(seed):
     torch.set_num_threads(1)
     import sga_amd
     from oracle.sga_oracle import SGAOracle
-    w = sga_amd.make_synthetic_weights(CFG["C"], seed=CFG["weight_seed"])
+    w = sga_amd.make_synthetic_weights(CFG["C"], seed=CFG["weight_seed"], bb=bool(CFG.get("bb")))
     x = make_inputs(CFG)
     t = time.time()
-    y_hat, z_hat, m, _ = SGAOracle(w).run(x, CFG["lmbda"], its=CFG["its"], seed=seed)
-    return dict(seed=seed, seconds=time.time() - t,
-                est_bpp=m["est_bpp"].astype(np.float64).tolist(), psnr=m["psnr"].astype(np.float64).tolist(),
-                est_y_bpp=m["est_y_bpp"].astype(np.float64).tolist(),
-                est_z_bpp=m["est_z_bpp"].astype(np.float64).tolist(), mse=m["mse"].astype(np.float64).tolist(),
-                y_hat_sum=float(np.abs(y_hat).sum()), z_hat_sum=float(np.abs(z_hat).sum()))
+    if CFG.get("bb"):
+        y_hat, z_hat, m, _, _ = SGAOracle(w).bb_run(x, CFG["lmbda"], its=CFG["its"], r_its=CFG["r_its"], seed=seed)
+    else:
+        y_hat, z_hat, m, _ = SGAOracle(w).run(x, CFG["lmbda"], its=CFG["its"], seed=seed)
+    out = dict(seed=seed, seconds=time.time() - t,
+               est_bpp=m["est_bpp"].astype(np.float64).tolist(), psnr=m["psnr"].astype(np.float64).tolist(),
+               est_y_bpp=m["est_y_bpp"].astype(np.float64).tolist(),
+               est_z_bpp=m["est_z_bpp"].astype(np.float64).tolist(), mse=m["mse"].astype(np.float64).tolist(),
+               y_hat_sum=float(np.abs(y_hat).sum()), z_hat_sum=float(np.abs(z_hat).sum()))
+    if CFG.get("bb"):
+        out["est_bpp_back"] = m["est_bpp_back"].astype(np.float64).tolist()
+    return out
 
 
 def main():
