@@ -27,9 +27,10 @@ TOL_BPP, TOL_PSNR = 1e-3, 0.01          # north_star tolerance
 
 # the small set (C = 64, 4 x 64^2, 32 seeds), one at the north star's width (C = 192, 2 x 128^2, 64 seeds), and cfg 5:
 # the complete two-stage bits-back run of bb_sga.py:199-276 (C = 64, 2 x 64^2, 2000 + 2000 iterations, 32 seeds)
-# and a ragged set (3 x 50 x 70: latents 4 x 5 and 1 x 2, every crop live in all 2000 steps)
+# a ragged set (3 x 50 x 70: latents 4 x 5 and 1 x 2, every crop live in all 2000 steps) and one at cfg 4's rate
+# point (lambda = 0.08)
 @pytest.mark.parametrize("golden", ["full_run_oracle.json", "full_run_oracle_c192.json", "full_run_oracle_bb.json",
-                                    "full_run_oracle_ragged.json"])
+                                    "full_run_oracle_ragged.json", "full_run_oracle_hirate.json"])
 def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir, golden):
     from sga_amd.codec import SGACodec, metrics_to_dict
     with open(os.path.join(ROOT, "tests", "golden", golden)) as f:

@@ -29,6 +29,8 @@ CFGS = {
     "": dict(C=64, B=4, H=64, W=64, its=2000, lmbda=0.01, x_seed=6, weight_seed=0, seeds=list(range(32))),
     # sizes that are not multiples of 16 / 64: every crop (x_tilde to x, mu / sigma to y) is live for all 2000 steps
     "ragged": dict(C=64, B=3, H=50, W=70, its=2000, lmbda=0.01, x_seed=9, weight_seed=0, seeds=list(range(32))),
+    # cfg 4's rate point (lambda = 0.08, README.md:60,105): the latents span more bins, the distortion term dominates
+    "hirate": dict(C=64, B=4, H=64, W=64, its=2000, lmbda=0.08, x_seed=10, weight_seed=0, seeds=list(range(32))),
     # cfg 5 (bb_sga.py:199-276): both stages, 2000 + 2000 iterations, bits-back weights (hyper-analysis emits mean | logvar)
     "bb": dict(C=64, B=2, H=64, W=64, its=2000, r_its=2000, lmbda=0.01, x_seed=8, weight_seed=0, bb=True,
                seeds=list(range(32))),
