@@ -23,8 +23,9 @@ from multiprocessing import Pool
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-# two sets: the small one (C = 64, 4 x 64^2, 32 seeds) and one at the north star's width (C = 192, 2 x 128^2,
-# 64 seeds; ~6 min per seed on one core):  GOLDEN=c192 NPROC=7 python tests/tools/make_golden_full_run.py
+# the sets (GOLDEN=<name> NPROC=7 python tests/tools/make_golden_full_run.py -> full_run_oracle_<name>.json): the small
+# one ("": C = 64, 4 x 64^2; ~1 min per seed on one core), ragged sizes, cfg 4's lambda, cfg 5's two-stage run, and one at the
+# north star's width (c192: C = 192, 2 x 128^2, ~5 min per seed on one core)
 CFGS = {
     "": dict(C=64, B=4, H=64, W=64, its=2000, lmbda=0.01, x_seed=6, weight_seed=0, seeds=list(range(32))),
     # sizes that are not multiples of 16 / 64: every crop (x_tilde to x, mu / sigma to y) is live for all 2000 steps
