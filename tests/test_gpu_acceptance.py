@@ -32,6 +32,15 @@ TOL_BPP, TOL_PSNR = 1e-3, 0.01          # north_star tolerance
 @pytest.mark.parametrize("golden", ["full_run_oracle.json", "full_run_oracle_c192.json", "full_run_oracle_bb.json",
                                     "full_run_oracle_ragged.json", "full_run_oracle_hirate.json"])
 def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir, golden):
+    _acceptance(gpu_out_dir, golden, "f32", "")
+
+
+def test_full_run_bf16x3_mode_within_north_star_tolerance(gpu_out_dir):
+    """The opt-in precision mode (exact 3 x bf16 operand split; not the headline) on the small set."""
+    _acceptance(gpu_out_dir, "full_run_oracle.json", "bf16x3", "_bf16x3")
+
+
+def _acceptance(gpu_out_dir, golden, precision, tag):
     from sga_amd.codec import SGACodec, metrics_to_dict
     with open(os.path.join(ROOT, "tests", "golden", golden)) as f:
         gold = json.load(f)
@@ -40,7 +49,7 @@ def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir,
     x = np.random.RandomState(cfg["x_seed"]).rand(B, H, W, 3).astype(np.float32)
     bb = bool(cfg.get("bb"))
     w = sga_amd.make_synthetic_weights(C, seed=cfg["weight_seed"], bb=bb)
-    codec = SGACodec(w, C, B, H, W, precision="f32", bits_back=bb)
+    codec = SGACodec(w, C, B, H, W, precision=precision, bits_back=bb)
     d_bpp, d_psnr, hip_bpp, hip_psnr, d_back = [], [], [], [], []
     for run in gold["runs"]:
         if bb:
@@ -72,7 +81,7 @@ def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir,
         d_back = np.array(d_back)
         rep.update(mean_d_bpp_back=float(d_back.mean()), sem_d_bpp_back=float(d_back.std(ddof=1) / np.sqrt(n)),
                    max_abs_d_bpp_back=float(np.abs(d_back).max()))
-    with open(os.path.join(gpu_out_dir, golden.replace("full_run_oracle", "acceptance_full_run")), "w") as f:
+    with open(os.path.join(gpu_out_dir, golden.replace("full_run_oracle", "acceptance_full_run").replace(".json", tag + ".json")), "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps(rep))
     # the north-star tolerance, on the means (standard errors stated in the report: ~3e-4 bpp, ~1e-3 dB)
