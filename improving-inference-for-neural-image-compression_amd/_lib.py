@@ -11,7 +11,7 @@ import os
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libsga_hip.so")
 
-SGA_ABI_VERSION = 2
+SGA_ABI_VERSION = 3
 
 STATUS = {
     0: "SGA_OK", -1: "SGA_ERR_BAD_ARG", -2: "SGA_ERR_BAD_SHAPE", -3: "SGA_ERR_UNSUPPORTED",
@@ -26,7 +26,7 @@ LAYERS = {name: i for i, name in enumerate(
 class SgaConfig(C.Structure):
     _fields_ = [("num_filters", C.c_int32), ("max_batch", C.c_int32), ("max_height", C.c_int32),
                 ("max_width", C.c_int32), ("bits_back", C.c_int32), ("precision", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("scale_bound", C.c_float), ("reserved", C.c_int32)]
 
 
 _FP = C.POINTER(C.c_float)
@@ -88,6 +88,9 @@ SYMBOLS["sga_bb_run"] = (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _I, _D, _D, _D, _I
 SYMBOLS["sga_bb_eval"] = (_I, [_P, _P, _I, _I, _I, _P, _P, _P, C.c_uint64, _P, _P])
 SYMBOLS["sga_op_factorized_density"] = (_I, [_P, _P, _I64, _P, _P, _P])
 SYMBOLS["sga_set_relaxation"] = (_I, [_P, _I, _I])
+SYMBOLS["sga_set_scale_bound"] = (_I, [_P, _F])
+# sga_config.scale_bound (include/sga_hip.h): NONE mirrors sga.py:130-133 (tfc layer never built), BUILT mbt2018.py:77-80
+SCALE_BOUND_NONE, SCALE_BOUND_BUILT = 0.0, 0.11
 SYMBOLS["sga_op_rate_terms"] = (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P])
 SYMBOLS["sga_set_image_ids"] = (_I, [_P, C.POINTER(C.c_int32), _I])
 PRECISIONS = {"default": 0, "f32": 1, "bf16x3": 2}

@@ -31,7 +31,11 @@ def _ptr(t):
 class SGACodec:
     def __init__(self, weights: dict, num_filters: int, max_batch: int, max_height: int,
                  max_width: int, device: str | torch.device = "cuda:0", bits_back: bool = False,
-                 precision: str = "default"):
+                 precision: str = "default", scale_bound: float = _lib.SCALE_BOUND_NONE):
+        """scale_bound: lower bound on the conditional's sigma in step / run / evaluate.  0 (default) mirrors
+        sga.py:130-133 and its siblings, which call `_likelihood` on a tfc layer that is never built (tfc 1.3 bounds
+        the scale in build()); 0.11 mirrors a built layer, mbt2018.py:77-80 (`base_compress` switches to it for the
+        call).  include/sga_hip.h, SGA_SCALE_BOUND_*."""
         if not torch.cuda.is_available():
             raise RuntimeError("SGACodec needs a ROCm GPU (gfx950); there is no CPU fallback")
         self.lib = _lib.load_library()
@@ -50,8 +54,9 @@ class SGACodec:
         # a dedicated non-null stream: hipGraph capture is not allowed on the legacy null stream
         self.stream = torch.cuda.Stream(device=self.device)
         self.precision = precision
+        self.scale_bound = float(scale_bound)
         cfg = _lib.SgaConfig(self.C, self.max_batch, self.max_height, self.max_width, int(bits_back),
-                             _lib.PRECISIONS[precision])
+                             _lib.PRECISIONS[precision], self.scale_bound, 0)
         w = _lib.SgaWeights()
         keep = []
 
@@ -125,6 +130,11 @@ class SGACodec:
         """Sibling inference methods on the same step (danneal.py / unoise.py / ste.py / map.py)."""
         self._chk(self.lib.sga_set_relaxation(self.handle, _lib.RELAXATIONS[relaxation],
                                               _lib.SCHEDULES[schedule]), "sga_set_relaxation")
+
+    def set_scale_bound(self, scale_bound: float):
+        """Change the sigma bound of the live handle (drops its cached step graphs)."""
+        self._chk(self.lib.sga_set_scale_bound(self.handle, float(scale_bound)), "sga_set_scale_bound")
+        self.scale_bound = float(scale_bound)
 
     def set_image_ids(self, ids=None):
         """Positions of this codec's images in their reference batch (None: 0,1,2,...): the device
@@ -257,16 +267,23 @@ class SGACodec:
         self._exit()
         return (met, xh) if want_x_hat else met
 
-    def base_compress(self, x, medians=None):
-        """mbt2018.py compress, estimated-rate path (cfg 1)."""
+    def base_compress(self, x, medians=None, scale_bound: float = _lib.SCALE_BOUND_BUILT):
+        """mbt2018.py compress, estimated-rate path (cfg 1).  mbt2018.py:80 CALLS the conditional layer, so tfc builds
+        it and bounds sigma below by scale_table[0] = 0.11: the handle's bound is switched to `scale_bound` for the
+        call and restored afterwards."""
         x = self._t(x)
         B, H, W, ys, zs = self._shapes(x)
         med = self._t(medians, (self.C,)) if medians is not None else None
         y_hat, z_hat, met = self._empty(*ys), self._empty(*zs), self._empty(B, 7)
-        s = self._enter()
-        self._chk(self.lib.sga_base_compress(self.handle, _ptr(x), B, H, W, _ptr(med), _ptr(y_hat),
-                                             _ptr(z_hat), _ptr(met), s), "sga_base_compress")
-        self._exit()
+        keep = self.scale_bound
+        self.set_scale_bound(scale_bound)
+        try:
+            s = self._enter()
+            self._chk(self.lib.sga_base_compress(self.handle, _ptr(x), B, H, W, _ptr(med), _ptr(y_hat),
+                                                 _ptr(z_hat), _ptr(met), s), "sga_base_compress")
+            self._exit()
+        finally:
+            self.set_scale_bound(keep)
         return y_hat, z_hat, met
 
     # ---- bb_sga.py (cfg 5): SGA + bits-back; needs bits_back=True ---------------------------------
@@ -365,21 +382,28 @@ class SGACodec:
             self._ec_dev = device_tables
         return self._ec
 
-    def compress_latents(self, x_shape, y_hat, z_hat) -> bytes:
-        """Entropy-code (y_hat, z_hat) of a batch into one byte string (cf. tfc.PackedTensors)."""
+    def compress_latents(self, x_shape, y_hat, z_hat, device_tables=True) -> bytes:
+        """Entropy-code (y_hat, z_hat) of a batch into one byte string (cf. tfc.PackedTensors).  The stream records
+        how its tables were built and their CRC32; device_tables=False gives the float64 host tables, which do
+        not depend on the GPU's math library (the interchange mode)."""
         from . import entropy_coding as ec
-        coder = self._entropy_coder()
+        coder = self._entropy_coder(device_tables=device_tables)
         y_hat, z_hat = self._t(y_hat), self._t(z_hat)
         mu, sigma = self.hyper_synthesis(z_hat, y_hat.shape[1], y_hat.shape[2])
         zb = coder.encode_z(z_hat.cpu().numpy())
         yb = coder.encode_y(y_hat.cpu().numpy(), mu.cpu().numpy(), sigma.cpu().numpy())
-        return ec.pack(tuple(x_shape), tuple(y_hat.shape), tuple(z_hat.shape), zb, yb)
+        return ec.pack(tuple(x_shape), tuple(y_hat.shape), tuple(z_hat.shape), zb, yb, coder.table_mode,
+                       coder.table_crc())
 
     def decompress_latents(self, blob: bytes):
         """-> (x_shape, y_hat, z_hat): z first, then (mu, sigma) = h_s(z_hat), then y."""
         from . import entropy_coding as ec
-        coder = self._entropy_coder()
-        x_shape, y_shape, z_shape, zb, yb = ec.unpack(blob)
+        x_shape, y_shape, z_shape, zb, yb, mode, crc = ec.unpack(blob, with_tables=True)
+        coder = self._entropy_coder(device_tables=bool(mode))
+        if coder.table_crc() != crc:
+            raise ValueError("SGAC stream was coded with different CDF tables (mode %d, crc %08x; this decoder builds "
+                             "%08x): other weights, or device-built tables from another GPU / ROCm build -- encode "
+                             "with device_tables=False for streams that must travel" % (mode, crc, coder.table_crc()))
         z_hat = self._t(coder.decode_z(zb, z_shape))
         mu, sigma = self.hyper_synthesis(z_hat, y_shape[1], y_shape[2])
         y_hat = self._t(coder.decode_y(yb, mu.cpu().numpy(), sigma.cpu().numpy()))

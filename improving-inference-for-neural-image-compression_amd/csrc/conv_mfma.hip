@@ -17,6 +17,7 @@
 //
 // f32 MFMA is a bitwise f32 fmaf chain (cdna_hip_programming.md s3), so results match an
 // f32 reference to summation-order rounding; no reduced precision anywhere.
+#include <atomic>
 #include <cstdio>
 
 #include "sga_common.h"
@@ -773,11 +774,15 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr int POST_FLOATS = POST ? (128 * (BN + 4) + 2 * BN * LDK) : 0;
   constexpr int F0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   const size_t lds = (size_t)(F0 > POST_FLOATS ? F0 : POST_FLOATS) * sizeof(float) + BM * sizeof(long long);
-  static bool attr_set = false;
-  if (!attr_set) {
+  // once per (instance, device): a process may drive several GPUs, and handles may live on several threads
+  static std::atomic<unsigned long long> attr_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC, X3, POST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_devs.fetch_or(bit, std::memory_order_release);
   }
   int grid = a.nphase * a.tiles_per_phase * a.ntiles_n;
   if (a.ksplit > 1) {

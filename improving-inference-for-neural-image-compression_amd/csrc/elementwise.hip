@@ -11,7 +11,6 @@ namespace {
 
 constexpr float kEps = 1e-5f;          // sga.py:30
 constexpr float kLikBound = 1e-9f;     // sga.py:28 / tfc likelihood_bound
-constexpr float kScaleMin = 0.11f;     // sga.py:24
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 constexpr float kInvSqrt2Pi = 0.3989422804014327f;
 
@@ -369,15 +368,19 @@ __global__ void k_bb_zgrad(const float* __restrict__ ga, const float* __restrict
 
 // ------------------------------------------------------------------------------------------
 // Gaussian conditional, box-convolved (utils.py:80-102 == tfc GaussianConditional._likelihood):
-//   sigma = max(exp(sraw), 0.11);  v = |y - mu|
+//   sigma = max(exp(sraw), smin);  v = |y - mu|
 //   p = Phi((.5 - v)/sigma) - Phi((-.5 - v)/sigma),  Phi(t) = erfc(-t/sqrt2)/2
+// smin = the handle's scale_bound (sga_config.scale_bound / sga_set_scale_bound): 0 = raw sigma, what sga.py:130-133
+// evaluates (the tfc layer is never built there); 0.11 = tfc's default bound scale_table[0] of a BUILT layer
+// (mbt2018.py:77-80).  exp(.) > 0, so smin = 0 needs no branch: max(sigma, 0) = sigma and the lower_bound gradient
+// rule (math_ops.py:63-76) passes everything.
 // ------------------------------------------------------------------------------------------
 struct GaussOut { float p, dp_dy, dp_dmu, dp_dsig_b, sigma; };
 
-__device__ __forceinline__ GaussOut gauss_mass(float y, float mu, float sraw) {
+__device__ __forceinline__ GaussOut gauss_mass(float y, float mu, float sraw, float smin) {
   GaussOut o;
   const float sigma = expf(sraw);
-  const float sb = fmaxf(sigma, kScaleMin);
+  const float sb = fmaxf(sigma, smin);
   const float d = y - mu;
   const float v = fabsf(d);
   const float up = (0.5f - v) / sb, lo = (-0.5f - v) / sb;
@@ -397,7 +400,7 @@ __device__ __forceinline__ GaussOut gauss_mass(float y, float mu, float sraw) {
 
 __global__ void k_gaussian(const float* __restrict__ yt, const float* __restrict__ ms,
                            const StepCtx* __restrict__ ctx, int h, int w, int hs, int ws, int C,
-                           float inv_ln2_hw, ImgSums* __restrict__ sums,
+                           float inv_ln2_hw, float smin, ImgSums* __restrict__ sums,
                            float* __restrict__ g_yt, float* __restrict__ g_ms) {
   __shared__ double sh[16];
   const int b = blockIdx.y;
@@ -411,14 +414,14 @@ __global__ void k_gaussian(const float* __restrict__ yt, const float* __restrict
     const size_t mo = ((size_t)(b * hs + i) * ws + j) * (2 * C) + c;
     if (i < h && j < w) {
       const size_t yo = ((size_t)(b * h + i) * w + j) * C + c;
-      const GaussOut o = gauss_mass(yt[yo], ms[mo], ms[mo + C]);
+      const GaussOut o = gauss_mass(yt[yo], ms[mo], ms[mo + C], smin);
       const float pb = fmaxf(o.p, kLikBound);
       nats[0] += (double)(-logf(pb));
       const float gp = lower_bound_grad(o.p, kLikBound, -ls * inv_ln2_hw / pb);
       if (g_yt) g_yt[yo] = gp * o.dp_dy;
       if (g_ms) {
         g_ms[mo] = gp * o.dp_dmu;
-        const float gsb = lower_bound_grad(o.sigma, kScaleMin, gp * o.dp_dsig_b);
+        const float gsb = lower_bound_grad(o.sigma, smin, gp * o.dp_dsig_b);
         g_ms[mo + C] = gsb * o.sigma;       // d sigma / d sraw = sigma
       }
     } else if (g_ms) {
@@ -431,17 +434,17 @@ __global__ void k_gaussian(const float* __restrict__ yt, const float* __restrict
 }
 
 __global__ void k_gaussian_op(const float* __restrict__ y, const float* __restrict__ mu,
-                              const float* __restrict__ sraw, int64_t n, float* __restrict__ p,
+                              const float* __restrict__ sraw, int64_t n, float smin, float* __restrict__ p,
                               float* __restrict__ dy, float* __restrict__ dmu,
                               float* __restrict__ dsr) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const GaussOut o = gauss_mass(y[i], mu[i], sraw[i]);
+    const GaussOut o = gauss_mass(y[i], mu[i], sraw[i], smin);
     if (p) p[i] = o.p;
     if (dy) dy[i] = o.dp_dy;
     if (dmu) dmu[i] = o.dp_dmu;
     // unit form: straight derivative of max(exp(sraw), bound) (no upstream sign available)
-    if (dsr) dsr[i] = (o.sigma >= kScaleMin) ? o.dp_dsig_b * o.sigma : 0.f;
+    if (dsr) dsr[i] = (o.sigma >= smin) ? o.dp_dsig_b * o.sigma : 0.f;
   }
 }
 
@@ -845,17 +848,17 @@ int launch_factorized(const float* zt, const float* eb_packed, const StepCtx* ct
 }
 
 int launch_gaussian(const float* yt, const float* ms, const StepCtx* ctx, int B, int h, int w,
-                    int hs, int ws, int C, float inv_ln2_hw, ImgSums* sums, float* g_yt,
+                    int hs, int ws, int C, float inv_ln2_hw, float scale_bound, ImgSums* sums, float* g_yt,
                     float* g_ms, hipStream_t s) {
   const int n_per_img = hs * ws * C;
   hipLaunchKernelGGL(k_gaussian, dim3(grid_for(n_per_img, 256, 512), B), dim3(256), 0, s, yt, ms,
-                     ctx, h, w, hs, ws, C, inv_ln2_hw, sums, g_yt, g_ms);
+                     ctx, h, w, hs, ws, C, inv_ln2_hw, scale_bound, sums, g_yt, g_ms);
   LAUNCH_RET();
 }
 
-int launch_gaussian_op(const float* y, const float* mu, const float* sraw, int64_t n, float* p,
-                       float* dp_dy, float* dp_dmu, float* dp_dsraw, hipStream_t s) {
-  hipLaunchKernelGGL(k_gaussian_op, dim3(grid_for(n)), dim3(256), 0, s, y, mu, sraw, n, p, dp_dy,
+int launch_gaussian_op(const float* y, const float* mu, const float* sraw, int64_t n, float scale_bound,
+                       float* p, float* dp_dy, float* dp_dmu, float* dp_dsraw, hipStream_t s) {
+  hipLaunchKernelGGL(k_gaussian_op, dim3(grid_for(n)), dim3(256), 0, s, y, mu, sraw, n, scale_bound, p, dp_dy,
                      dp_dmu, dp_dsraw);
   LAUNCH_RET();
 }

@@ -19,6 +19,7 @@
 // LDS: tile [BM][C+4] (pitch = 4 mod 64 banks: conflict-free ds_read_b128 fragments, conflict-free
 // C-layout scatter) + one K-step of gamma [C][36]; BM = 64, C = 192: 78 KB -> 2 workgroups per CU,
 // so one workgroup's loads/stores overlap the other's MFMAs.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -318,11 +319,15 @@ template <int NC, int WM, int WN, int MODE, int PRO>
 int launch_inst(const GdnArgs& a, hipStream_t stream) {
   constexpr int C = NC * 32, BM = WM * 32, NT = WM * WN * 64;
   const size_t lds = (size_t)(BM * (C + 4) + C * LDK) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  // once per (instance, device): a process may drive several GPUs, and handles may live on several threads
+  static std::atomic<unsigned long long> attr_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_tile_kernel<NC, WM, WN, MODE, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_devs.fetch_or(bit, std::memory_order_release);
   }
   const long long grid = (a.M + BM - 1) / BM;
   if (grid <= 0 || grid > 0x7fffffffLL) return (int)hipErrorInvalidValue;

@@ -31,12 +31,13 @@ int launch_factorized(const float* zt, const float* eb_packed, const StepCtx* ct
 
 // Gaussian conditional on y_tilde [B,h,w,C] with (mu | sigma_raw) = ms [B,hs,ws,2C] cropped to
 // [h,w] (sga.py:126-136).  Writes g_yt (rate term), g_ms [B,hs,ws,2C] (zero outside the crop).
+// scale_bound: lower bound on sigma with the lower_bound gradient rule; 0 = none (sga_config.scale_bound)
 int launch_gaussian(const float* yt, const float* ms, const StepCtx* ctx, int B, int h, int w,
-                    int hs, int ws, int C, float inv_ln2_hw, ImgSums* sums, float* g_yt,
+                    int hs, int ws, int C, float inv_ln2_hw, float scale_bound, ImgSums* sums, float* g_yt,
                     float* g_ms, hipStream_t s);
 // unit-parity form: flat arrays, returns p and partials
-int launch_gaussian_op(const float* y, const float* mu, const float* sraw, int64_t n, float* p,
-                       float* dp_dy, float* dp_dmu, float* dp_dsraw, hipStream_t s);
+int launch_gaussian_op(const float* y, const float* mu, const float* sraw, int64_t n, float scale_bound,
+                       float* p, float* dp_dy, float* dp_dmu, float* dp_dsraw, hipStream_t s);
 
 // distortion: sums + gradient image g = lambda*2*255^2*loss_scale/(HW3) * (xt - x) written into
 // the zero-bordered buffer gpad [B,Hp,Wp,3] at offset (2,2)  (sga.py:150-161)

@@ -61,6 +61,7 @@ Geom make_geom(int B, int H, int W) {
 struct sga_handle {
   sga_config cfg;
   int C = 0, C15 = 0, C2 = 0, haN = 0;
+  float scale_bound = 0.f;         // lower bound on the conditional's sigma (sga_config.scale_bound, sga_set_scale_bound); 0 = none
   int last_hip_error = 0;
   char last_msg[256] = {0};
 
@@ -896,7 +897,7 @@ int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, b
   SGACHK(deconv_fwd(h, h->hs_f[1], h->hs_bias[1], h->hs0.p, B, 2 * g.zh, 2 * g.zw, h->hs1.p, EPI_BIAS_RELU, st));
   h->cur_tag = "hs2.fwd";
   SGACHK(conv3(h, h->hs_f[2], h->hs_bias[2], h->hs1.p, h->C15, B, g.hsh, g.hsw, h->ms.p, true, EPI_BIAS, nullptr, st));
-  HIPCHK(h, launch_gaussian(h->yt.p, h->ms.p, h->ctx, B, g.yh, g.yw, g.hsh, g.hsw, C, il, h->sums,
+  HIPCHK(h, launch_gaussian(h->yt.p, h->ms.p, h->ctx, B, g.yh, g.yw, g.hsh, g.hsw, C, il, h->scale_bound, h->sums,
                             with_grad ? h->g_yt_rate.p : nullptr, with_grad ? h->g_ms.p : nullptr, st));
   if (!with_grad) return SGA_OK;
   h->cur_tag = "hs2.bwd";
@@ -1117,11 +1118,13 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   *out = nullptr;
   if (cfg->num_filters <= 0 || cfg->num_filters % 64 != 0) return SGA_ERR_UNSUPPORTED;
   if (cfg->max_batch <= 0 || cfg->max_height <= 0 || cfg->max_width <= 0) return SGA_ERR_BAD_ARG;
+  if (!(cfg->scale_bound >= 0.f) || !(cfg->scale_bound < 1e30f)) return SGA_ERR_BAD_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return SGA_ERR_NO_DEVICE;
   sga_handle* h = new (std::nothrow) sga_handle();
   if (!h) return SGA_ERR_NOMEM;
   h->cfg = *cfg;
+  h->scale_bound = cfg->scale_bound;
   const int C = cfg->num_filters;
   h->C = C; h->C15 = (int)(C * 1.5); h->C2 = 2 * C;
   h->haN = cfg->bits_back ? 2 * C : C;
@@ -1347,6 +1350,9 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   if (env) h->side_target = atoi(env);
   env = getenv("SGA_FUSED_GDN");
   h->fused_gdn = !(env && env[0] == '0');
+  // gdn_fused.hip has instances for C / 32 in {2, 4, 6, 8}; wider models (num_filters = 320, 384, ...) take the generic
+  // gather-GEMM GDN with an ordinary split-K reduce (conv_mfma.hip tiles any channel count)
+  if (C / 32 != 2 && C / 32 != 4 && C / 32 != 6 && C / 32 != 8) h->fused_gdn = false;
   env = getenv("SGA_FUSED_POST");
   h->fused_post = !(env && env[0] == '0');
   env = getenv("SGA_PLAN_TILES");
@@ -1799,7 +1805,7 @@ int sga_op_gaussian_likelihood(sga_handle* h, const float* y, const float* mu,
                                const float* sigma_raw, int64_t n, float* p, float* dp_dy,
                                float* dp_dmu, float* dp_dsraw, void* stream) {
   if (!h || !y || !mu || !sigma_raw || n <= 0) return SGA_ERR_BAD_ARG;
-  HIPCHK(h, launch_gaussian_op(y, mu, sigma_raw, n, p, dp_dy, dp_dmu, dp_dsraw, (hipStream_t)stream));
+  HIPCHK(h, launch_gaussian_op(y, mu, sigma_raw, n, h->scale_bound, p, dp_dy, dp_dmu, dp_dsraw, (hipStream_t)stream));
   return SGA_OK;
 }
 
@@ -1820,12 +1826,25 @@ int sga_op_rate_terms(sga_handle* h, const float* y_tilde, const float* z_tilde,
   HIPCHK(h, launch_fill((float*)h->sums, 0.f, (int64_t)(sizeof(ImgSums) / sizeof(float)) * B, st));
   HIPCHK(h, launch_factorized(z_tilde, h->eb_packed, h->ctx, B, g.zh * g.zw, h->C, il, h->sums, g_zt, nullptr,
                               nullptr, st));
-  HIPCHK(h, launch_gaussian(y_tilde, ms, h->ctx, B, g.yh, g.yw, g.hsh, g.hsw, h->C, il, h->sums, g_yt, g_ms, st));
+  HIPCHK(h, launch_gaussian(y_tilde, ms, h->ctx, B, g.yh, g.yw, g.hsh, g.hsw, h->C, il, h->scale_bound, h->sums, g_yt,
+                            g_ms, st));
   if (metrics) {   // [B][7] in the order of sga.py:183; only est_bpp / est_y_bpp / est_z_bpp are meaningful
     HIPCHK(h, launch_finalize_eval(h->sums, B, H, W, metrics, st));
   } else {
     HIPCHK(h, launch_fill((float*)h->sums, 0.f, (int64_t)(sizeof(ImgSums) / sizeof(float)) * B, st));
   }
+  return SGA_OK;
+}
+
+// The bound is a launch argument of k_gaussian, i.e. part of every captured step graph: drop them.
+int sga_set_scale_bound(sga_handle* h, float scale_bound) {
+  if (!h || !(scale_bound >= 0.f) || !(scale_bound < 1e30f)) return SGA_ERR_BAD_ARG;
+  if (scale_bound == h->scale_bound) return SGA_OK;
+  HIPCHK(h, hipDeviceSynchronize());
+  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  for (int k = 0; k < 2; ++k)
+    if (h->bb_graph[k]) { (void)hipGraphExecDestroy(h->bb_graph[k]); h->bb_graph[k] = nullptr; }
+  h->scale_bound = scale_bound;
   return SGA_OK;
 }
 

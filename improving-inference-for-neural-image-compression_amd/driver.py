@@ -196,7 +196,7 @@ def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, los
 
 def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=700, T_ub=0.5,
                 seed=0, rank=0, world=1, dist=None, verbose=False, log_itv=100, log=print,
-                method="sga", r_its=2000, r_lr=0.003, medians=None):
+                method="sga", r_its=2000, r_lr=0.003, medians=None, base_scale_bound=None):
     """The per-batch loop of sga.py:201-253 (method "sga"), bb_sga.py:199-280 ("bb_sga") or the
     one-shot mbt2018.py:159-180 ("mbt2018") over a dataset X [N,H,W,3] float32.
     Returns dict field -> [N] array (on every rank)."""
@@ -207,56 +207,60 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
     if method in ("mbt2018", "map") and medians is None:
         medians = getattr(codec, "medians", None)       # from the checkpoint's `quantiles`
     log_sched, log_rate, log_Tub, log_t0 = "exp0", annealing_rate, T_ub, t0
-    for b_i, batch in enumerate(reference_batches(N, bs)):
-        mine = shard_batch(batch, rank, world, b_i)
-        loss_scale = 1.0 / len(batch)                   # the batch means of sga.py:147,150
-        # one noise stream per reference batch; an image's noise is keyed on its position in that
-        # batch (sga_set_image_ids), so results do not depend on world size or chunking
-        sd = seed + 1000003 * b_i
-        for s in range(0, len(mine), codec.max_batch):  # workspace-sized chunks of the shard
-            idx = mine[s:s + codec.max_batch]
-            codec.set_image_ids([i - batch[0] for i in idx])
-            if method == "bb_sga":
-                _, _, met, tr, _ = codec.bb_run(X[idx], lmbda, its=its, r_its=r_its, lr=lr, r_lr=r_lr,
-                                                annealing_rate=annealing_rate, t0=t0, T_ub=T_ub,
-                                                seed=sd, loss_scale=loss_scale, trace=verbose)
-            elif method == "mbt2018":
-                _, _, met = codec.base_compress(X[idx], medians=medians)
-                tr = None
-            elif method in SIBLINGS:
-                relax, sched, s_lr, s_r, s_Tub, s_t0, early = SIBLINGS[method]
-                log_sched, log_rate, log_Tub, log_t0 = sched, s_r, s_Tub, s_t0
-                codec.set_relaxation(relax, sched)
-                try:
-                    if early:
-                        _, _, met, _ = run_early_stop(codec, X[idx], lmbda, method=method, its=its, lr=s_lr,
-                                                      seed=sd, loss_scale=loss_scale, medians=medians,
-                                                      log=log if verbose else None)
-                        tr = None
-                    else:
-                        _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=s_lr, annealing_rate=s_r,
-                                                  t0=s_t0, T_ub=s_Tub, seed=sd, loss_scale=loss_scale,
-                                                  trace=verbose)
-                finally:
-                    codec.set_relaxation("sga", "exp0")
-            elif verbose:
-                met = run_verbose(codec, X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate, t0=t0,
-                                  T_ub=T_ub, seed=sd, loss_scale=loss_scale, log_itv=log_itv, log=log)
-                tr = None
-            else:
-                _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate,
-                                          t0=t0, T_ub=T_ub, seed=sd, loss_scale=loss_scale,
-                                          trace=verbose)
-            if verbose and tr is not None:
-                tr = tr.cpu().numpy()
-                for it in range(its):
-                    if it % log_itv == 0 or it + 1 == its:      # sga.py:216,232-233
-                        T = annealed_temperature(it, log_rate, log_Tub, scheme=log_sched, t0=log_t0)
-                        log("it=%d, T=%.3f rd_loss=%.4f mse=%.3f bpp=%.4f psnr=%.4f" %
-                            (it, T, tr[it, 0], tr[it, 1], tr[it, 2], tr[it, 3]))
-            local_idx += idx
-            local_met.append(met.cpu().numpy())
-    codec.set_image_ids(None)
+    try:
+        for b_i, batch in enumerate(reference_batches(N, bs)):
+            mine = shard_batch(batch, rank, world, b_i)
+            loss_scale = 1.0 / len(batch)                   # the batch means of sga.py:147,150
+            # one noise stream per reference batch; an image's noise is keyed on its position in that
+            # batch (sga_set_image_ids), so results do not depend on world size or chunking
+            sd = seed + 1000003 * b_i
+            for s in range(0, len(mine), codec.max_batch):  # workspace-sized chunks of the shard
+                idx = mine[s:s + codec.max_batch]
+                codec.set_image_ids([i - batch[0] for i in idx])
+                if method == "bb_sga":
+                    _, _, met, tr, _ = codec.bb_run(X[idx], lmbda, its=its, r_its=r_its, lr=lr, r_lr=r_lr,
+                                                    annealing_rate=annealing_rate, t0=t0, T_ub=T_ub,
+                                                    seed=sd, loss_scale=loss_scale, trace=verbose)
+                elif method == "mbt2018":
+                    kw = {} if base_scale_bound is None else dict(scale_bound=base_scale_bound)
+                    _, _, met = codec.base_compress(X[idx], medians=medians, **kw)      # default 0.11: mbt2018.py:80
+                    tr = None
+                elif method in SIBLINGS:
+                    relax, sched, s_lr, s_r, s_Tub, s_t0, early = SIBLINGS[method]
+                    log_sched, log_rate, log_Tub, log_t0 = sched, s_r, s_Tub, s_t0
+                    codec.set_relaxation(relax, sched)
+                    try:
+                        if early:
+                            _, _, met, _ = run_early_stop(codec, X[idx], lmbda, method=method, its=its, lr=s_lr,
+                                                          seed=sd, loss_scale=loss_scale, medians=medians,
+                                                          log=log if verbose else None)
+                            tr = None
+                        else:
+                            _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=s_lr, annealing_rate=s_r,
+                                                      t0=s_t0, T_ub=s_Tub, seed=sd, loss_scale=loss_scale,
+                                                      trace=verbose)
+                    finally:
+                        codec.set_relaxation("sga", "exp0")
+                elif verbose:
+                    met = run_verbose(codec, X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate, t0=t0,
+                                      T_ub=T_ub, seed=sd, loss_scale=loss_scale, log_itv=log_itv, log=log)
+                    tr = None
+                else:
+                    _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate,
+                                              t0=t0, T_ub=T_ub, seed=sd, loss_scale=loss_scale,
+                                              trace=verbose)
+                if verbose and tr is not None:
+                    tr = tr.cpu().numpy()
+                    for it in range(its):
+                        if it % log_itv == 0 or it + 1 == its:      # sga.py:216,232-233
+                            T = annealed_temperature(it, log_rate, log_Tub, scheme=log_sched, t0=log_t0)
+                            log("it=%d, T=%.3f rd_loss=%.4f mse=%.3f bpp=%.4f psnr=%.4f" %
+                                (it, T, tr[it, 0], tr[it, 1], tr[it, 2], tr[it, 3]))
+                local_idx += idx
+                local_met.append(met.cpu().numpy())
+    finally:
+        # an exception in a run must not leave the handle drawing noise for stale batch positions
+        codec.set_image_ids(None)
     local_met = np.concatenate(local_met, 0) if local_met else np.zeros((0, len(fields)), np.float32)
     device = codec.device if (dist is not None and dist.is_initialized()
                               and dist.get_backend() == "nccl") else None
@@ -285,6 +289,10 @@ def parse_args(argv):
     c.add_argument("--synthetic_weights", action="store_true",
                    help="use the deterministic synthetic parameters instead of a checkpoint")
     c.add_argument("--max_batch", type=int, default=0, help="images per GPU launch (0 = reference batch)")
+    c.add_argument("--scale_bound", type=float, default=None,
+                   help="lower bound on the conditional's sigma; default: what the mirrored script executes -- none (0) "
+                        "for sga.py and its siblings, which never build the tfc GaussianConditional layer "
+                        "(sga.py:130-133), 0.11 for mbt2018.py, which calls it (mbt2018.py:77-80)")
     c.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
                    help="arithmetic of the conv contractions (DESIGN.md 3.1b); f32 = fp32 MFMA")
     c.add_argument("runname")
@@ -328,11 +336,13 @@ def compress(args, weights=None):
     bs = get_eval_batch_size(H * W)
     per_rank = -(-min(bs, N) // world)
     max_batch = args.max_batch or per_rank
+    sb = getattr(args, "scale_bound", None)
     codec = SGACodec(weights, args.num_filters, max_batch, H, W, device=f"cuda:{local_rank}",
-                     bits_back=bb, precision=getattr(args, "precision", "f32"))
+                     bits_back=bb, precision=getattr(args, "precision", "f32"),
+                     scale_bound=0.0 if sb is None else sb)
     res = run_dataset(codec, X, args.lmbda, its=args.sga_its, annealing_rate=args.annealing_rate,
                       t0=args.t0, seed=args.seed, rank=rank, world=world, dist=dist,
-                      verbose=args.verbose, method=method)
+                      verbose=args.verbose, method=method, base_scale_bound=sb)
     if rank == 0:
         if args.results_dir:
             os.makedirs(args.results_dir, exist_ok=True)

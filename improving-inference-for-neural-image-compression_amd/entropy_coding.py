@@ -164,6 +164,15 @@ class EntropyCoder:
             self.cdf[i, t.size:] = TOTAL
         self.lens = np.asarray(lens, np.int32)
         self.offs = np.asarray(offs, np.int32)
+        self.table_mode = 1 if device_models is not None else 0
+        self._crc = None
+
+    def table_crc(self) -> int:
+        """CRC32 over every quantised CDF table: the fingerprint a stream carries (`pack`) and a decoder checks."""
+        if self._crc is None:
+            import zlib
+            self._crc = zlib.crc32(np.ascontiguousarray(self.cdf).tobytes() + self.lens.tobytes() + self.offs.tobytes())
+        return self._crc
 
     # ---- symbol/table preparation ---------------------------------------------------------------
     def _y_symbols(self, y_hat, mu, sigma):
@@ -243,20 +252,31 @@ class EntropyCoder:
         return float(-np.log2(f / TOTAL).sum() + 32.0 * esc.sum())
 
 
-def pack(x_shape, y_shape, z_shape, z_bytes: bytes, y_bytes: bytes) -> bytes:
-    """Container (cf. tfc.PackedTensors, mbt2018.py:211-214): magic, shapes, two length-prefixed streams."""
-    head = MAGIC + struct.pack("<3I4I4I", *x_shape, *y_shape, *z_shape)
+FORMAT_VERSION = 2      # 1 (round 2, magic only) had no table fingerprint
+
+
+def pack(x_shape, y_shape, z_shape, z_bytes: bytes, y_bytes: bytes, table_mode: int = 0, table_crc: int = 0) -> bytes:
+    """Container (cf. tfc.PackedTensors, mbt2018.py:211-214): magic, format version, how the coder's CDF tables were
+    built (0 = host float64 numpy, 1 = device float32 kernels) and their CRC32, shapes, two length-prefixed streams.
+    A range coder needs bit-identical tables on both sides: the decoder refuses a stream whose fingerprint is not its own."""
+    head = MAGIC + struct.pack("<BBHI", FORMAT_VERSION, table_mode, 0, table_crc & 0xFFFFFFFF)
+    head += struct.pack("<3I4I4I", *x_shape, *y_shape, *z_shape)
     return head + struct.pack("<I", len(z_bytes)) + z_bytes + struct.pack("<I", len(y_bytes)) + y_bytes
 
 
-def unpack(blob: bytes):
+def unpack(blob: bytes, with_tables: bool = False):
     if blob[:4] != MAGIC:
         raise ValueError("not an SGAC stream")
-    v = struct.unpack("<3I4I4I", blob[4:48])
+    version, table_mode, _, table_crc = struct.unpack("<BBHI", blob[4:12])
+    if version != FORMAT_VERSION:
+        raise ValueError(f"SGAC stream format {version}, this build reads format {FORMAT_VERSION}")
+    v = struct.unpack("<3I4I4I", blob[12:56])
     x_shape, y_shape, z_shape = v[:3], v[3:7], v[7:11]
-    p = 48
+    p = 56
     (nz,) = struct.unpack("<I", blob[p:p + 4]); p += 4
     z_bytes = blob[p:p + nz]; p += nz
     (ny,) = struct.unpack("<I", blob[p:p + 4]); p += 4
     y_bytes = blob[p:p + ny]
+    if with_tables:
+        return x_shape, y_shape, z_shape, z_bytes, y_bytes, table_mode, table_crc
     return x_shape, y_shape, z_shape, z_bytes, y_bytes

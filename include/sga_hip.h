@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGA_ABI_VERSION 2
+#define SGA_ABI_VERSION 3
 
 typedef enum sga_status {
   SGA_OK = 0,
@@ -55,8 +55,24 @@ typedef struct sga_config {
   int32_t max_width;
   int32_t bits_back;     /* 0: mbt2018 (sga.py); 1: mbt2018_bb, h_a emits 2C (bb_sga.py:69) */
   int32_t precision;     /* sga_precision; 0 = default (SGA_PRECISION env: "f32" | "bf16x3", else f32) */
-  int32_t reserved[2];
+  float scale_bound;     /* lower bound on the conditional's sigma = exp(sigma_raw), with the lower_bound gradient
+                          * rule (math_ops.py:63-76); 0 = none.  See SGA_SCALE_BOUND_* below.  (ABI v3; was reserved[0]) */
+  int32_t reserved;
 } sga_config;
+
+/* Which bound mirrors the reference?  tfc 1.3's GaussianConditional applies
+ * `scale = lower_bound(scale, scale_table[0])` in SymmetricConditional.build(), and only a __call__ of the
+ * layer runs build().
+ *   SGA_SCALE_BOUND_NONE  (0)     sga.py:130-133, bb_sga.py:121-124, danneal.py:127-130, unoise.py:90-93, ste.py:105-108,
+ *                                 map.py:93-96: the layer is constructed and `_likelihood` is called directly -- never
+ *                                 built -- so these scripts evaluate the RAW sigma.  The default of a zeroed config.
+ *   SGA_SCALE_BOUND_BUILT (0.11)  mbt2018.py:77-80 calls the layer (`conditional_bottleneck(y, training=...)`): sigma is
+ *                                 bounded below by scale_table[0] = SCALES_MIN = 0.11 (mbt2018.py:30-32,77).  Set this
+ *                                 for sga_base_compress.
+ * PROVISIONAL: stated from tfc 1.3's source as remembered, not from a run (TF 1.15 / tfc 1.3 are not installable in the
+ * build container); INTEGRATION.md section 5 has the two-line check for a TF box.  Both modes are parity-tested. */
+#define SGA_SCALE_BOUND_NONE 0.0f
+#define SGA_SCALE_BOUND_BUILT 0.11f
 
 /* Arithmetic of the convolution contractions.  Both modes take f32 operands and accumulate in f32:
  *  F32_MFMA : v_mfma_f32_32x32x2_f32, a bitwise f32 fmaf chain.
@@ -90,6 +106,9 @@ int sga_destroy(sga_handle* h);
 int sga_last_error(const sga_handle* h, char* msg, int msg_len);
 /* latent geometry for an HxW image: y is [h,w,C], z is [hz,wz,C] (sga.py:77-78) */
 int sga_latent_shape(const sga_handle* h, int H, int W, int* yh, int* yw, int* zh, int* zw);
+/* change sga_config.scale_bound of a live handle (e.g. SGA_SCALE_BOUND_BUILT around sga_base_compress on a handle
+ * that otherwise runs SGA).  Synchronises the device and drops the cached step graphs. */
+int sga_set_scale_bound(sga_handle* h, float scale_bound);
 
 /* ---- sharding: which images of the reference batch does this handle hold? ----
  * The reference draws the Gumbel noise of a whole batch from one op (sga.py:95-97,118-120), so an
@@ -156,7 +175,9 @@ int sga_quantize_centered(sga_handle* h, const float* y, const float* z, int B, 
 int sga_eval(sga_handle* h, const float* x, int B, int H, int W,
              const float* y_hat, const float* z_hat, float* metrics, float* x_hat, void* stream);
 
-/* ---- mbt2018.py:64-81,167-180 (cfg 1, estimated-rate path): one-shot encode ------------- */
+/* ---- mbt2018.py:64-81,167-180 (cfg 1, estimated-rate path): one-shot encode -------------
+ * mbt2018.py:80 calls the conditional layer, so the reference bounds sigma here: use a handle with
+ * scale_bound = SGA_SCALE_BOUND_BUILT (or sga_set_scale_bound around the call) to mirror it. */
 int sga_base_compress(sga_handle* h, const float* x, int B, int H, int W, const float* medians,
                       float* y_hat, float* z_hat, float* metrics, void* stream);
 
@@ -227,7 +248,7 @@ int sga_op_sample(sga_handle* h, const float* v, const float* u, int64_t n, floa
 int sga_op_factorized_likelihood(sga_handle* h, const float* v, int64_t n_pix,
                                  float* p, float* dp_dv, void* stream);
 /* box-convolved Gaussian mass (sga.py:130-133, utils.py:80-102) and its partials
- * w.r.t. y, mu and sigma_raw (sigma = exp(sigma_raw), bounded below by 0.11) */
+ * w.r.t. y, mu and sigma_raw (sigma = max(exp(sigma_raw), the handle's scale_bound)) */
 int sga_op_gaussian_likelihood(sga_handle* h, const float* y, const float* mu,
                                const float* sigma_raw, int64_t n,
                                float* p, float* dp_dy, float* dp_dmu, float* dp_dsraw,

@@ -66,5 +66,14 @@ def test_container_and_corruption(coder):
     assert xs == (1, 64, 64) and zs == z.shape and zb2 == zb and yb2 == b"abc"
     with pytest.raises(ValueError):
         ec.unpack(b"nope" + blob[4:])
+    # format version and table fingerprint travel with the stream (a range coder needs identical tables)
+    blob = ec.pack((1, 64, 64), (1, 4, 4, 64), z.shape, zb, b"abc", coder.table_mode, coder.table_crc())
+    *_, mode, crc = ec.unpack(blob, with_tables=True)
+    assert mode == 0 and crc == coder.table_crc() and crc != 0
+    import sga_amd
+    w2 = sga_amd.make_synthetic_weights(64, seed=1)                    # another model: another fingerprint
+    assert ec.EntropyCoder({k: v for k, v in w2.items() if k.startswith("eb.")}).table_crc() != crc
+    with pytest.raises(ValueError):
+        ec.unpack(blob[:4] + bytes([1]) + blob[5:])            # a round-2 (format 1) stream is refused
     with pytest.raises(ValueError):
         coder.decode_z(zb[:3], z.shape)

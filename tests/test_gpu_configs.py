@@ -27,17 +27,22 @@ def report(gpu_out_dir, **kw):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
-@pytest.mark.parametrize("C,H,W,f64", [(192, 512, 768, True), (192, 768, 512, True), (256, 1200, 1200, False),
-                                       (256, 96, 80, True)])
-def test_step_at_config_shape(C, H, W, f64, precision, gpu_out_dir):
+@pytest.mark.parametrize("C,H,W,f64,sb", [(192, 512, 768, True, 0.0), (192, 768, 512, True, 0.0),
+                                          (256, 1200, 1200, False, 0.11), (256, 1200, 1200, False, 0.0),
+                                          (256, 96, 80, True, 0.0), (256, 96, 80, True, 0.11)])
+def test_step_at_config_shape(C, H, W, f64, sb, precision, gpu_out_dir):
     """encode + one SGA evaluation with Philox noise vs the oracle (float64 where it fits in a few
     seconds; the float32 oracle's own gz is only good to ~1e-2 at Kodak size, the HIP path agrees
-    with float64 to 3e-6 there)."""
+    with float64 to 3e-6 there).  sb = sga_config.scale_bound.  At Tecnick size only the float32 oracle is
+    affordable, and there the two modes need different tolerances: the untrained C = 256 weights predict scales
+    down to 7e-4, and with the raw sigma of sga.py:130-133 (sb = 0) an element at |y - mu| ~ 0.5 has
+    d(-log p)/dy ~ 1/sigma -- the float32 rounding of mu (1e-6) moves its gradient by 1e-6 / sigma ~ 1e-3 in either
+    float32 implementation; bounded at 0.11 the same step agrees to 2e-5."""
     from sga_amd.codec import SGACodec, metrics_to_dict
     w = sga_amd.make_synthetic_weights(C, seed=0)
     x = np.random.RandomState(1).rand(1, H, W, 3).astype(np.float32)
-    orc = SGAOracle(w, dtype=torch.float64 if f64 else torch.float32)
-    codec = SGACodec(w, C, 1, H, W, precision=precision)
+    orc = SGAOracle(w, dtype=torch.float64 if f64 else torch.float32, scale_bound=sb)
+    codec = SGACodec(w, C, 1, H, W, precision=precision, scale_bound=sb)
     yo, zo = SGAOracle(w).encode(x)
     y, z = codec.encode(x)
     assert tuple(y.shape) == (1, -(-H // 16), -(-W // 16), C) and tuple(z.shape) == (1, -(-H // 64), -(-W // 64), C)
@@ -50,9 +55,11 @@ def test_step_at_config_shape(C, H, W, f64, precision, gpu_out_dir):
     errs = dict(enc_y=e_enc[0], enc_z=e_enc[1], gy=rel_err(got["gy"].cpu().numpy(), want["gy"].numpy()),
                 gz=rel_err(got["gz"].cpu().numpy(), want["gz"].numpy()),
                 rd_loss=abs(float(got["rd_loss"]) / float(want["rd_loss"]) - 1))
-    report(gpu_out_dir, test="config_step", C=C, H=H, W=W, precision=precision, **errs)
+    report(gpu_out_dir, test="config_step", C=C, H=H, W=W, precision=precision, scale_bound=sb, **errs)
     assert errs["enc_y"] < 2e-5 and errs["enc_z"] < 2e-5, errs
-    assert errs["gy"] < 1e-4 and errs["gz"] < (1e-4 if f64 else 5e-4) and errs["rd_loss"] < 1e-5, errs
+    ill = (not f64) and sb == 0.0          # float32 oracle + raw sigma down to 7e-4: see the docstring
+    assert errs["gy"] < (1e-3 if ill else 1e-4) and errs["gz"] < (1e-4 if f64 else (5e-3 if ill else 5e-4)), errs
+    assert errs["rd_loss"] < 1e-5, errs
     # a short complete run at this shape: finite metrics, objective improves, reproducible
     a = codec.run(x, lmbda, its=40, t0=10, annealing_rate=0.02, seed=2)
     b = codec.run(x, lmbda, its=40, t0=10, annealing_rate=0.02, seed=2)

@@ -27,6 +27,21 @@ def get_codec(C, precision="f32"):
 
 
 PRECISIONS = ["f32", "bf16x3"]   # v_mfma_f32_32x32x2_f32 chain / exact 3 x bf16 operand split, same tolerances
+# sga_config.scale_bound: 0 = raw sigma (sga.py:130-133, tfc layer never built), 0.11 = built layer (mbt2018.py:77-80)
+SCALE_BOUNDS = [0.0, 0.11]
+
+
+class scale_bound_of:
+    """Run a block with the shared codec's sigma bound set to `sb`; restore the default (0) afterwards."""
+
+    def __init__(self, codec, sb):
+        self.codec, self.sb = codec, sb
+
+    def __enter__(self):
+        self.codec.set_scale_bound(self.sb)
+
+    def __exit__(self, *exc):
+        self.codec.set_scale_bound(0.0)
 
 
 def rel_err(a, b):
@@ -166,27 +181,32 @@ def test_factorized_likelihood(gpu_out_dir):
     assert np.allclose(mass.cpu().numpy().sum(0), 1.0, atol=1e-3)
 
 
-def test_gaussian_likelihood(gpu_out_dir):
+@pytest.mark.parametrize("sb", SCALE_BOUNDS)
+def test_gaussian_likelihood(sb, gpu_out_dir):
     codec, orc, orc64, _ = get_codec(64)
     rng = np.random.RandomState(3)
     n = 20000
     y = (rng.standard_normal(n) * 4).astype(np.float32)
     mu = rng.standard_normal(n).astype(np.float32)
     sr = (rng.standard_normal(n) * 1.2).astype(np.float32)
-    sr[:100] = -4.0            # sigma below the 0.11 bound
+    sr[:100] = -4.0            # sigma = 0.018, below the 0.11 bound
     y[:50] = mu[:50]           # |y - mu| = 0: sign() = 0
     yt, mt, st = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (y, mu, sr))
     # straight max() on sigma for the unit op (no upstream sign): d/dsraw = 0 below the bound
-    sigma = torch.clamp_min(torch.exp(st), 0.11)
+    sigma = torch.clamp_min(torch.exp(st), sb) if sb > 0 else torch.exp(st)
     v = torch.abs(yt - mt)
     c = 2.0 ** -0.5
     p = 0.5 * torch.erfc(-c * ((0.5 - v) / sigma)) - 0.5 * torch.erfc(-c * ((-0.5 - v) / sigma))
     dy, dm, ds = torch.autograd.grad(p.sum(), [yt, mt, st])
-    gp, gdy, gdm, gds = (t.cpu().numpy() for t in codec.gaussian_likelihood(y, mu, sr))
+    with scale_bound_of(codec, sb):
+        gp, gdy, gdm, gds = (t.cpu().numpy() for t in codec.gaussian_likelihood(y, mu, sr))
     errs = dict(p=rel_err(gp, p.detach().numpy()), dy=rel_err(gdy, dy.numpy()),
                 dmu=rel_err(gdm, dm.numpy()), dsr=rel_err(gds, ds.numpy()))
-    report(gpu_out_dir, "gaussian", **errs)
+    report(gpu_out_dir, "gaussian", scale_bound=sb, **errs)
     assert errs["p"] < 1e-5 and errs["dy"] < 5e-5 and errs["dmu"] < 5e-5 and errs["dsr"] < 5e-5, errs
+    # the two modes really differ on the 100 small-sigma elements and nowhere else
+    bounded = torch.clamp_min(torch.exp(st), 0.11).detach().numpy() != torch.exp(st).detach().numpy()
+    assert bounded[:100].all() and (gds[:100] == 0).all() == (sb > 0)
     # symmetry p(mu+d) = p(mu-d) and sum_k p = 1
     d = np.float32(1.37)
     a, *_ = codec.gaussian_likelihood(mu + d, mu, sr)
@@ -197,15 +217,20 @@ def test_gaussian_likelihood(gpu_out_dir):
     assert abs(float(tot.sum()) - 1.0) < 1e-4
 
 
-def test_gaussian_likelihood_reference_fixture():
+@pytest.mark.parametrize("sb", SCALE_BOUNDS)
+def test_gaussian_likelihood_reference_fixture(sb):
     """sga_op_gaussian_likelihood vs the outputs of the reference's own
-    utils.box_convolved_gaussian_pdf (tests/golden/utils_reference.npz; float64 there, f32 here)."""
+    utils.box_convolved_gaussian_pdf (tests/golden/utils_reference.npz; float64 there, f32 here).
+    The vendored formula takes sigma as given: with scale_bound = 0 every fixture row applies (incl.
+    sigma = 1e-3), with 0.11 the rows at or above the bound."""
     codec, *_ = get_codec(64)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "utils_reference.npz"))
-    ok = g["box_sigma"] >= 0.11                 # below: the op applies the scale bound of sga.py:129
+    ok = g["box_sigma"] >= sb
+    assert (~ok).any() == (sb > 0)
     y, mu, sigma, want = (g[k][ok] for k in ("box_y", "box_mu", "box_sigma", "box_out"))
-    p, *_ = codec.gaussian_likelihood(y.astype(np.float32), mu.astype(np.float32),
-                                      np.log(sigma).astype(np.float32))
+    with scale_bound_of(codec, sb):
+        p, *_ = codec.gaussian_likelihood(y.astype(np.float32), mu.astype(np.float32),
+                                          np.log(sigma).astype(np.float32))
     p = p.cpu().numpy().astype(np.float64)
     # inputs rounded to f32 move p by up to ~|dp/dy| * 2^-24 |y|: compare with a mixed tolerance
     assert np.allclose(p, want, rtol=2e-4, atol=1e-7), float(np.abs(p - want).max())
@@ -252,13 +277,15 @@ def test_factorized_prior_vs_reference_executed_fixture(gpu_out_dir):
     assert tail.sum() > 50 and (p[tail] > 0).all() and np.allclose(p[tail], fx["mass_sign_trick"][tail], rtol=1e-3, atol=0)
 
 
-def test_lower_bound_branches_in_the_step_kernels(gpu_out_dir):
+@pytest.mark.parametrize("sb", SCALE_BOUNDS)
+def test_lower_bound_branches_in_the_step_kernels(sb, gpu_out_dir):
     """math_ops.py:63-76 inside the kernels of the SGA step (k_gaussian / k_factorized, driven through
     sga_op_rate_terms with fed intermediates): every combination of
-      sigma below / above scale_bound = 0.11 (sga.py:129)   x   sign of the gradient reaching sigma,
+      sigma below / above 0.11   x   sign of the gradient reaching sigma,
       p below / above likelihood_bound = 1e-9 (sga.py:134-136, 102-104),
     against float64 autograd of the oracle, whose bound gradient is pinned to the reference-executed
-    fixture (tests/test_oracle.py)."""
+    fixture (tests/test_oracle.py).  sb = 0.11: a built tfc layer (mbt2018.py:77-80), the small sigmas are
+    bounded and their gradient follows the rule; sb = 0: sga.py:130-133, raw sigma, every gradient passes."""
     codec, o64, _ = _prior_fixture_codec()
     C, B, H, W = codec.C, 1, 64, 64
     yh, yw, zh, zw = codec.latent_shape(H, W)
@@ -282,14 +309,15 @@ def test_lower_bound_branches_in_the_step_kernels(gpu_out_dir):
     # z_tilde: bulk plus far-tail values where the factorized mass is below 1e-9
     zt = (rng.standard_normal((B, zh, zw, C)) * 3).astype(np.float32)
     zt[..., ::5] = np.where(rng.rand(B, zh, zw, len(range(0, C, 5))) < 0.5, -400.0, 400.0)
-    got = codec.rate_terms(yt, zt, ms, H, W, loss_scale=1.0)
+    with scale_bound_of(codec, sb):
+        got = codec.rate_terms(yt, zt, ms, H, W, loss_scale=1.0)
     # float64 oracle of the same sub-graph (sga.py:100-104, 126-146)
     from oracle.sga_oracle import LIKELIHOOD_BOUND
     ytt = torch.tensor(yt, dtype=torch.float64, requires_grad=True)
     ztt = torch.tensor(zt, dtype=torch.float64, requires_grad=True)
     mst = torch.tensor(ms, dtype=torch.float64, requires_grad=True)
     mu_t, sr_t = mst[..., :C][:, :yh, :yw], mst[..., C:][:, :yh, :yw]
-    p_y_raw = o64.gauss_likelihood(ytt, mu_t, torch.exp(sr_t))
+    p_y_raw = o64.gauss_likelihood(ytt, mu_t, torch.exp(sr_t), sb)
     p_z_raw = o64.eb_likelihood(ztt)
     p_y, p_z = lower_bound(p_y_raw, LIKELIHOOD_BOUND), lower_bound(p_z_raw, LIKELIHOOD_BOUND)
     den = np.log(2.0) * H * W
@@ -300,8 +328,14 @@ def test_lower_bound_branches_in_the_step_kernels(gpu_out_dir):
     assert (pr[..., k == 4] < 3e-10).all() and (pr[..., k == 4] > 0).all() and (pr[..., k == 5] < 1e-30).all()
     assert (p_z_raw.detach().numpy()[..., ::5] < 1e-12).all()
     gs = g_ms[..., C:][:, :yh, :yw].numpy()
-    assert (gs[..., k == 0] == 0).all()                                  # blocked
-    assert (gs[..., k == 1] < 0).all() and (gs[..., k == 2] > 0).all() and (gs[..., k == 3] < 0).all()
+    if sb > 0:
+        assert (gs[..., k == 0] == 0).all()                              # blocked
+        assert (gs[..., k == 1] < 0).all()
+    else:
+        # raw sigma = 0.05: the mass at distance 0 is 1 - 2e-23 (its sigma-gradient passes but underflows);
+        # at distance 0.7 the box [0.2, 1.2] sigma away holds 3e-5 of the mass and grows fast with sigma
+        assert (gs[..., k == 1] < 0).all() and (pr[..., k == 1] < 1e-4).all()
+    assert (gs[..., k == 2] > 0).all() and (gs[..., k == 3] < 0).all()
     assert (gs[..., k == 4] != 0).all()                                   # bounded p still has a gradient
     for name, a, b_, tol in (("g_yt", got["g_yt"], g_yt, 2e-4), ("g_ms", got["g_ms"], g_ms, 2e-4),
                              ("g_zt", got["g_zt"], g_zt, 1e-3)):     # deep-tail dp/dv in float32: 4e-4
@@ -314,7 +348,8 @@ def test_lower_bound_branches_in_the_step_kernels(gpu_out_dir):
         assert np.allclose(a, b_, rtol=tol, atol=tol * 1e-3 * scale), (name, where_bad(a, b_, tol))
     # exact zeros where the rule blocks, also in float32
     a = got["g_ms"].cpu().numpy()[..., C:][:, :yh, :yw]
-    assert (a[..., k == 0] == 0).all()
+    if sb > 0:
+        assert (a[..., k == 0] == 0).all()
     assert np.allclose(got["est_y_bpp"].cpu().numpy(), [float(y_bpp.detach())], rtol=2e-5)
     assert np.allclose(got["est_z_bpp"].cpu().numpy(), [float(z_bpp.detach())], rtol=2e-5)
 

@@ -90,6 +90,89 @@ def test_step_grads_injected_noise(C, B, H, W, T, precision, gpu_out_dir):
     assert np.allclose(got["psnr"].cpu().numpy(), ref["psnr"].numpy(), atol=2e-3)
 
 
+def low_sigma_weights(C):
+    """Synthetic weights whose predicted scales straddle 0.11 (h_s output bias of the log-scale half
+    lowered by 2.5: sigma ~ 0.03 ... 0.5), so that sga_config.scale_bound changes the objective."""
+    w = dict(sga_amd.make_synthetic_weights(C, seed=0))
+    b2 = w["hs.b2"].copy()
+    b2[C:] -= 2.5
+    w["hs.b2"] = b2
+    return w
+
+
+@pytest.mark.parametrize("sb", [0.0, 0.11])
+@pytest.mark.parametrize("C,B,H,W", [(64, 2, 64, 64), (192, 1, 50, 70)])
+def test_step_grads_both_scale_bound_modes(C, B, H, W, sb, gpu_out_dir):
+    """The complete step with sigma on both sides of 0.11, in both modes of sga_config.scale_bound, vs
+    float64 autograd of the oracle in the same mode: 0 = sga.py:130-133 (tfc layer never built, raw
+    sigma), 0.11 = a built layer (mbt2018.py:77-80; lower_bound with its gradient rule on sigma).  The
+    two modes must also DIFFER here (a test on the usual weights, sigma >= 0.3, could not tell them apart)."""
+    from sga_amd.codec import SGACodec
+    w = low_sigma_weights(C)
+    codec = SGACodec(w, C, B, H, W, scale_bound=sb)
+    orc, orc64 = SGAOracle(w), SGAOracle(w, dtype=torch.float64, scale_bound=sb)
+    other64 = SGAOracle(w, dtype=torch.float64, scale_bound=0.11 - sb)
+    x = image(B, H, W, seed=61)
+    yo, zo = orc.encode(x)
+    rng = np.random.RandomState(62)
+    y0 = (yo.numpy() + 0.3 * rng.standard_normal(tuple(yo.shape))).astype(np.float32)
+    z0 = (zo.numpy() + 0.3 * rng.standard_normal(tuple(zo.shape))).astype(np.float32)
+    u_y = rng.uniform(1e-4, 1 - 1e-4, (y0.size, 2)).astype(np.float32)
+    u_z = rng.uniform(1e-4, 1 - 1e-4, (z0.size, 2)).astype(np.float32)
+    ref = orc64.step(x, y0, z0, 0.3, u_y, u_z, 0.01)
+    oth = other64.step(x, y0, z0, 0.3, u_y, u_z, 0.01)
+    sig = torch.exp(orc64.hyper_synthesis(ref["z_tilde"])[..., C:])
+    frac_below = float((sig < 0.11).double().mean())
+    assert 0.02 < frac_below < 0.98, frac_below
+    got = codec.step_grads(x, y0, z0, 0.3, 0.01, u_y=u_y, u_z=u_z)
+    ey = rel_err(got["gy"].cpu().numpy(), ref["gy"].numpy())
+    ez = rel_err(got["gz"].cpu().numpy(), ref["gz"].numpy())
+    report(gpu_out_dir, "step_grads_scale_bound", C=C, scale_bound=sb, frac_sigma_below=frac_below, rel_err_gy=ey,
+           rel_err_gz=ez, train_bpp=got["train_bpp"], train_bpp_ref=ref["train_bpp"], train_bpp_other_mode=oth["train_bpp"])
+    assert ey < 1e-4 and ez < 1e-4, (ey, ez)
+    assert abs(got["train_bpp"] - ref["train_bpp"]) <= 2e-5 * abs(ref["train_bpp"])
+    assert abs(oth["train_bpp"] - ref["train_bpp"]) > 3e-3 * abs(ref["train_bpp"])     # the switch matters here
+    # the switch on a live handle == a handle created in that mode, through the graph replay as well
+    a = codec.run(x, 0.01, its=12, t0=4, annealing_rate=0.02, seed=5)
+    codec.set_scale_bound(0.11 - sb)
+    b = codec.run(x, 0.01, its=12, t0=4, annealing_rate=0.02, seed=5)
+    codec.set_scale_bound(sb)
+    c = codec.run(x, 0.01, its=12, t0=4, annealing_rate=0.02, seed=5)
+    assert torch.equal(a[0], c[0]) and torch.allclose(a[2], c[2], rtol=1e-6, atol=0, equal_nan=True)
+    assert not torch.allclose(a[2][:, 5], b[2][:, 5], rtol=1e-4, atol=0)        # est_y_bpp moves with the mode
+    # the evaluation of the rounded latents follows the mode too (sga.py:244-245 runs the same graph)
+    from sga_amd.codec import metrics_to_dict
+    m = metrics_to_dict(a[2])
+    want = SGAOracle(w, scale_bound=sb).evaluate(x, a[0].cpu().numpy(), a[1].cpu().numpy())
+    assert np.allclose(m["est_y_bpp"], want["est_y_bpp"], rtol=5e-5)
+    codec.close()
+
+
+def test_wide_model_outside_the_fused_gdn_instances(gpu_out_dir):
+    """num_filters = 320: gdn_fused.hip has instances for C / 32 in {2, 4, 6, 8} only, so the handle must fall back to
+    the generic gather-GEMM GDN (with an ordinary split-K reduce) instead of failing every launch: encode, one full
+    step vs float64 autograd and a short graph-replayed run."""
+    from sga_amd.codec import SGACodec
+    C, B, H, W = 320, 1, 48, 40
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    codec, orc, orc64 = SGACodec(w, C, B, H, W), SGAOracle(w), SGAOracle(w, dtype=torch.float64)
+    x = image(B, H, W, seed=71)
+    y, z = codec.encode(x)
+    yo, zo = orc.encode(x)
+    assert rel_err(y.cpu().numpy(), yo.numpy()) < 5e-5 and rel_err(z.cpu().numpy(), zo.numpy()) < 1e-4
+    rng = np.random.RandomState(72)
+    u_y = rng.uniform(1e-4, 1 - 1e-4, (yo.numel(), 2)).astype(np.float32)
+    u_z = rng.uniform(1e-4, 1 - 1e-4, (zo.numel(), 2)).astype(np.float32)
+    ref = orc64.step(x, yo.numpy(), zo.numpy(), 0.3, u_y, u_z, 0.01)
+    got = codec.step_grads(x, yo.numpy(), zo.numpy(), 0.3, 0.01, u_y=u_y, u_z=u_z)
+    ey, ez = rel_err(got["gy"].cpu().numpy(), ref["gy"].numpy()), rel_err(got["gz"].cpu().numpy(), ref["gz"].numpy())
+    report(gpu_out_dir, "step_grads_c320", rel_err_gy=ey, rel_err_gz=ez)
+    assert ey < 1e-4 and ez < 1e-4, (ey, ez)
+    _, _, met, tr = codec.run(x, 0.01, its=8, seed=1, trace=True)
+    assert torch.isfinite(tr).all() and torch.isfinite(met[:, [0, 1, 4]]).all()
+    codec.close()
+
+
 def test_step_grads_philox(gpu_out_dir):
     """Device Philox stream == oracle/philox.py: same gradients without injecting noise."""
     C, B, H, W = 64, 2, 64, 64
@@ -143,10 +226,18 @@ def test_base_compress(gpu_out_dir):
     """cfg 1 (mbt2018.py compress, estimated-rate path)."""
     from sga_amd.codec import metrics_to_dict
     C, B, H, W = 64, 1, 50, 70
-    codec, orc, _ = setup(C, B, H, W)
+    from sga_amd.codec import SGACodec
+    # scales on both sides of 0.11: mbt2018.py:80 calls the conditional layer, so sigma IS bounded here (both
+    # the codec and the oracle default to 0.11 for this entry point, whatever the handle's SGA-path setting)
+    w = low_sigma_weights(C)
+    codec, orc = SGACodec(w, C, B, H, W), SGAOracle(w)
+    assert codec.scale_bound == 0.0
     x = image(B, H, W, seed=5)
     y_hat, z_hat, met = codec.base_compress(x)
+    assert codec.scale_bound == 0.0                     # restored
     yo, zo, want = orc.base_compress(x)
+    raw = orc.base_compress(x, scale_bound=0.0)[2]
+    assert abs(raw["est_bpp"][0] / want["est_bpp"][0] - 1) > 3e-3
     # rounding can flip at exact .5 ties only: allow a handful of off-by-one latents
     ny = np.abs(y_hat.cpu().numpy() - yo.numpy()) > 1e-3
     assert ny.mean() < 1e-3

@@ -105,12 +105,17 @@ def test_utils_fixtures_from_reference():
     mine = SGAOracle.log_normal_pdf(*(torch.tensor(g[k]) for k in ("lnpdf_sample", "lnpdf_mean", "lnpdf_logvar")))
     assert mine.dtype == torch.float32
     assert np.allclose(mine.numpy(), g["lnpdf_out"], rtol=2e-6, atol=2e-6)
-    # box-convolved Gaussian (utils.py:86-102); the oracle adds the 0.11 scale bound of sga.py:129
+    # box-convolved Gaussian (utils.py:86-102): sigma as given (scale_bound = 0, what sga.py:130-133 evaluates:
+    # every row, incl. sigma = 1e-3); with the bound of a built tfc layer the rows at or above 0.11 are unchanged
+    # and the rows below it are evaluated at sigma = 0.11
     y, mu, sigma = (torch.tensor(g[k], dtype=torch.float64) for k in ("box_y", "box_mu", "box_sigma"))
     mine = SGAOracle.gauss_likelihood(y, mu, sigma).numpy()
+    assert np.allclose(mine, g["box_out"], rtol=1e-9, atol=1e-300)
     ok = g["box_sigma"] >= 0.11
-    assert ok.sum() >= 350
-    assert np.allclose(mine[ok], g["box_out"][ok], rtol=1e-9, atol=1e-300)
+    assert ok.sum() >= 350 and (~ok).sum() >= 1
+    bounded = SGAOracle.gauss_likelihood(y, mu, sigma, 0.11).numpy()
+    assert np.array_equal(bounded[ok], mine[ok])
+    assert np.allclose(bounded[~ok], SGAOracle.gauss_likelihood(y, mu, torch.full_like(sigma, 0.11))[~ok].numpy(), rtol=1e-12)
     # run names (utils.py:51-69) -> lambda (sga.py:158)
     with open(os.path.join(GOLDEN, "runnames.json")) as f:
         for case in json.load(f):

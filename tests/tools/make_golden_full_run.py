@@ -36,7 +36,20 @@ CFGS = {
     "bb": dict(C=64, B=2, H=64, W=64, its=2000, r_its=2000, lmbda=0.01, x_seed=8, weight_seed=0, bb=True,
                seeds=list(range(32))),
     "c192": dict(C=192, B=2, H=128, W=128, its=2000, lmbda=0.01, x_seed=7, weight_seed=0, seeds=list(range(64))),
+    # the BENCHMARKED geometry (BASELINE.json configs[1]: B = 8, 256^2, C = 192, lambda = 0.01): the only set on which the
+    # production kernel variants (256-row LDS-DMA tiles, IGDN post-phase, split 256-row gs2.bwd, two-stream graph) meet the
+    # oracle over all 2000 steps.  ~2.3 h per seed on ONE core (run 5 seeds on 5 cores in the background).  scale_bound = 0:
+    # sga.py never builds the GaussianConditional layer (oracle/sga_oracle.py, SGAOracle.__init__)
+    "cfg2": dict(C=192, B=8, H=256, W=256, its=2000, lmbda=0.01, x_seed=11, weight_seed=0, scale_bound=0.0,
+                 seeds=list(range(5))),
+    # CONTROL for the statistical criterion: the small set's inputs and Philox seeds through the float64 oracle.  The
+    # float32-vs-float64 ORACLE difference is what "a different rounding of the same arithmetic" does to a 2000-step run;
+    # tests/test_oracle.py asserts it has the spread the GPU acceptance test tolerates
+    "f64": dict(C=64, B=4, H=64, W=64, its=2000, lmbda=0.01, x_seed=6, weight_seed=0, dtype="float64",
+                seeds=list(range(32))),
 }
+for _c in CFGS.values():
+    _c.setdefault("scale_bound", 0.11)      # the sets of rounds 1-2 were generated with the bound hard-coded
 NAME = os.environ.get("GOLDEN", "")
 CFG = CFGS[NAME]
 if os.environ.get("NSEEDS"):
@@ -58,10 +71,13 @@ def one_seed(seed):
     w = sga_amd.make_synthetic_weights(CFG["C"], seed=CFG["weight_seed"], bb=bool(CFG.get("bb")))
     x = make_inputs(CFG)
     t = time.time()
+    orc = SGAOracle(w, dtype=getattr(torch, CFG.get("dtype", "float32")), scale_bound=CFG["scale_bound"])
     if CFG.get("bb"):
-        y_hat, z_hat, m, _, _ = SGAOracle(w).bb_run(x, CFG["lmbda"], its=CFG["its"], r_its=CFG["r_its"], seed=seed)
+        y_hat, z_hat, m, _, _ = orc.bb_run(x, CFG["lmbda"], its=CFG["its"], r_its=CFG["r_its"], seed=seed)
     else:
-        y_hat, z_hat, m, _ = SGAOracle(w).run(x, CFG["lmbda"], its=CFG["its"], seed=seed)
+        prog = (lambda it, st: print("seed %d it %d rd_loss %.4f %.0f s" % (seed, it, st["rd_loss"], time.time() - t),
+                                     flush=True)) if os.environ.get("PROGRESS") else None
+        y_hat, z_hat, m, _ = orc.run(x, CFG["lmbda"], its=CFG["its"], seed=seed, progress=prog)
     out = dict(seed=seed, seconds=time.time() - t,
                est_bpp=m["est_bpp"].astype(np.float64).tolist(), psnr=m["psnr"].astype(np.float64).tolist(),
                est_y_bpp=m["est_y_bpp"].astype(np.float64).tolist(),
@@ -86,18 +102,27 @@ def main():
         for r in pool.imap_unordered(one_seed, todo):
             have[r["seed"]] = r
             print("seed", r["seed"], "%.0f s" % r["seconds"], flush=True)
-    runs = [have[s] for s in CFG["seeds"]]
+            write([have[s] for s in CFG["seeds"] if s in have])      # a long job can be harvested early
+    write([have[s] for s in CFG["seeds"]])
+
+
+def write(runs):
+    import numpy as np
+    if len(runs) < 2:
+        return
+    cfg = dict(CFG, seeds=[r["seed"] for r in runs])
     bpp = np.array([r["est_bpp"] for r in runs])     # [seed, image]
     psnr = np.array([r["psnr"] for r in runs])
-    out = dict(config=CFG, runs=runs,
+    out = dict(config=cfg, runs=runs,
                oracle_seed_spread=dict(est_bpp_std_per_image=bpp.std(0, ddof=1).tolist(),
                                        psnr_std_per_image=psnr.std(0, ddof=1).tolist(),
                                        est_bpp_mean=float(bpp.mean()), psnr_mean=float(psnr.mean())),
                note="oracle = oracle/sga_oracle.py (PyTorch CPU f32, Philox noise); inputs = "
                     "RandomState(x_seed).rand(B,H,W,3) float32; weights = make_synthetic_weights(C, weight_seed)")
-    with open(OUT, "w") as f:
+    with open(OUT + ".tmp", "w") as f:
         json.dump(out, f, indent=1)
-    print("wrote", OUT)
+    os.replace(OUT + ".tmp", OUT)
+    print("wrote", OUT, len(runs), "seeds", flush=True)
 
 
 if __name__ == "__main__":
