@@ -14,8 +14,12 @@ collective is the final all_gather of the [8,7] metrics over RCCL (SURVEY.md 8(e
 Inputs are resident in HBM before the timed region.  The timed region replays the captured
 hipGraph of the step sequence; afterwards a short eager, hipEvent-instrumented run gives the
 dominant kernel's average duration for the `roofline` object (peak: 157.3 TFLOP/s fp32 MFMA,
-MI355X_MICROARCH.md), and -- at N=1 -- the CPU oracle is timed on the host cores for
-`cpu_baseline` (a PyTorch-CPU port of the same graph; the TF1 reference cannot run here).
+MI355X_MICROARCH.md) -- `roofline.achieved / frac` are that kernel ALONE on the chip, and
+`roofline.in_graph` is the same kernel bracketed by an event pair INSIDE the graph replay the
+headline times (second stream running beside it; sga_profile_graph_begin) -- and, at N=1, the CPU
+oracle is timed on the host cores for `cpu_baseline` (a PyTorch-CPU port of the same graph; the
+TF1 reference cannot run here).  `other_input` repeats one timed step on low-pass-filtered noise
+(the sustained MFMA clock depends on the operand data).
 """
 import argparse
 import json
@@ -105,6 +109,11 @@ def main():
                     help="also measure the other precision mode (opt-in; the bf16x3 mode is not part of the headline)")
     ap.add_argument("--dump-metrics", default="",
                     help="write the gathered [n_gpus*B, 7] metrics of the last timed step to this .npy (tests)")
+    ap.add_argument("--input", default="uniform", choices=["uniform", "natural"],
+                    help="synthetic input of the HEADLINE: uniform noise (BASELINE.json configs[1]) or low-pass-filtered "
+                         "noise ('natural-ish', SURVEY.md 8(d)); the other one is measured on one extra step and reported "
+                         "as `other_input`")
+    ap.add_argument("--no-other-input", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
@@ -112,7 +121,7 @@ def main():
                          "profiles/r01_c_roofline_leg_kernel_stats.csv was taken from with rocprofv3 --kernel-trace --stats)")
     args = ap.parse_args()
     if args.roofline_only:
-        args.warmup, args.steps, args.no_cpu_baseline, args.alt_precision = 0, 0, True, False
+        args.warmup, args.steps, args.no_cpu_baseline, args.alt_precision, args.no_other_input = 0, 0, True, False, True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -146,10 +155,22 @@ def main():
     weights = sga_amd.make_synthetic_weights(C, seed=0)
     codec = SGACodec(weights, C, B, H, W, device=device, precision=args.precision)
     gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    x = torch.rand(B, H, W, 3, generator=gen).to(device)     # resident in HBM before timing
+    x_uniform = torch.rand(B, H, W, 3, generator=gen)
 
-    def one_step(seed, cdc=None):
-        y_hat, z_hat, met, _ = (cdc or codec).run(x, args.lmbda, its=args.its, seed=seed)
+    def natural(u):
+        """Low-pass-filtered noise: two 9x9 box blurs of the uniform batch, each channel stretched back to [0, 1]."""
+        t = u.permute(0, 3, 1, 2)
+        for _ in range(2):
+            t = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(t, (4, 4, 4, 4), mode="reflect"), 9, 1)
+        lo, hi = t.amin(dim=(2, 3), keepdim=True), t.amax(dim=(2, 3), keepdim=True)
+        return ((t - lo) / (hi - lo)).permute(0, 2, 3, 1).contiguous()
+
+    inputs = {"uniform": x_uniform, "natural": natural(x_uniform)}
+    x = inputs[args.input].to(device)                         # resident in HBM before timing
+    x_other = inputs["natural" if args.input == "uniform" else "uniform"].to(device)
+
+    def one_step(seed, cdc=None, xin=None):
+        y_hat, z_hat, met, _ = (cdc or codec).run(x if xin is None else xin, args.lmbda, its=args.its, seed=seed)
         if dist is not None:     # result gather: the only collective on this path (RCCL)
             src = met if backend == "nccl" else met.cpu()
             out = [torch.empty_like(src) for _ in range(world)]
@@ -178,6 +199,18 @@ def main():
     n_images = world * B * args.steps
     value = n_images / elapsed if args.steps else 0.0
 
+    # ---- the other synthetic input, one timed step (N = 1 only) -------------------------------------
+    other_input = None
+    if rank == 0 and world == 1 and args.steps and not args.no_other_input:
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        met_o = one_step(100, xin=x_other)
+        torch.cuda.synchronize(device)
+        el = time.perf_counter() - t1
+        other_input = dict(input="natural" if args.input == "uniform" else "uniform", value=round(B / el, 4),
+                           ms_per_step=round(1e3 * el, 2), steps=1, final_est_bpp_mean=float(met_o[:, 4].mean()),
+                           final_psnr_mean=float(met_o[:, 1].mean()))
+
     # ---- roofline of the dominant kernel: live hipEvent timing over eager launches ----------
     roofline = None
     kernels = []
@@ -194,12 +227,27 @@ def main():
                             frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                             avg_launch_us=round(1e3 * k["ms_total"] / k["launches"], 2),
                             gflop_per_launch=round(k["flops_total"] / k["launches"] / 1e9, 4),
-                            launches=k["launches"], traffic=None)
+                            launches=k["launches"], traffic=None,
+                            note="achieved/frac: the kernel alone on the chip (eager launches, hipEvents on its stream); "
+                                 "in_graph: the same symbol inside the two-stream hipGraph replay that `value` times")
+            # the same symbol inside the graph replay (event-record nodes around its launch; 200 replays)
+            try:
+                codec.profile_graph_begin(k["name"])
+                codec.run(x, args.lmbda, its=min(args.its, 200), seed=7, metrics=False)
+                g = codec.profile_graph_end()
+                if g["launches"] > 0 and g["ms_total"] > 0:
+                    ag = g["flops_total"] / (g["ms_total"] * 1e-3) / 1e12
+                    roofline["in_graph"] = dict(achieved=round(ag, 3), frac=round(ag / FP32_MFMA_PEAK_TFLOPS, 4),
+                                                avg_launch_us=round(1e3 * g["ms_total"] / g["launches"], 2),
+                                                launches=g["launches"])
+            except Exception as e:      # measurement only: never fail the bench line for it
+                roofline["in_graph"] = dict(error=str(e)[:200])
     # ---- HBM traffic of the dominant kernel from the committed PMC profile (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 on gfx950; scripts/pmc_traffic.py) ------
     if roofline is not None:
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            import glob
+            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]) as f:
                 tr = json.load(f)
             ent = tr.get(roofline["kernel"])
             if ent:
@@ -259,7 +307,8 @@ def main():
                        "images_per_step": world * B, "sga_iterations": args.its,
                        "weights": "synthetic (make_synthetic_weights seed 0)",
                        "parallelism": f"images sharded over {world} GPU(s), RCCL all_gather of metrics"},
-            "precision": args.precision,
+            "precision": args.precision, "input": args.input,
+            "other_input": other_input,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "alt_precision": alt,

@@ -98,6 +98,8 @@ RELAXATIONS = {"sga": 0, "danneal": 1, "unoise": 2, "ste": 3, "none": 4}
 SCHEDULES = {"exp0": 0, "exp": 1}
 SYMBOLS["sga_profile_begin"] = (_I, [_P])
 SYMBOLS["sga_profile_end"] = (_I, [_P, C.POINTER(SgaKernelStat), _I, C.POINTER(_I)])
+SYMBOLS["sga_profile_graph_begin"] = (_I, [_P, C.c_char_p])
+SYMBOLS["sga_profile_graph_end"] = (_I, [_P, C.POINTER(SgaKernelStat)])
 
 _lib = None
 

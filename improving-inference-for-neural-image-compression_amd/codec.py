@@ -430,6 +430,16 @@ class SGACodec:
                      ms_total=float(arr[i].ms_total), flops_total=float(arr[i].flops_total))
                 for i in range(min(n.value, 64))]
 
+    def profile_graph_begin(self, kernel_name: str):
+        """Time one kernel symbol inside the hipGraph replay of the following run()s (sga_profile_graph_begin)."""
+        self._chk(self.lib.sga_profile_graph_begin(self.handle, kernel_name.encode()), "sga_profile_graph_begin")
+
+    def profile_graph_end(self):
+        st = _lib.SgaKernelStat()
+        self._chk(self.lib.sga_profile_graph_end(self.handle, C.byref(st)), "sga_profile_graph_end")
+        return dict(name=st.name.decode(), launches=int(st.launches), ms_total=float(st.ms_total),
+                    flops_total=float(st.flops_total))
+
     # ---- operator surface (unit parity) --------------------------------------------------------
     def layer_fwd(self, layer: str, inp):
         inp = self._t(inp)

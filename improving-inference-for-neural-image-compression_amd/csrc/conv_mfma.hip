@@ -118,11 +118,16 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int chunk = tid & 7, lrow = tid >> 3;
+  // measurement (sga_profile_graph_begin; null otherwise): earliest workgroup entry / latest workgroup exit of this
+  // launch on the 100 MHz wall clock -> the launch's duration inside a hipGraph replay, where no event can bracket it
+  if (a.stamp && tid == 0) atomicMin(&a.stamp[0], wall_clock64());
+#define SGA_STAMP_END() do { if (a.stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); \
+                                             if (tid == 0) atomicMax(&a.stamp[1], wall_clock64()); } } while (0)
 #ifdef SGA_CLOCK_PROBE
   const unsigned long long wallE = a.clk ? wall_clock64() : 0;
-#define SGA_PROBE_END() do { if (a.clk && tid == 0) a.clk[6 * blockIdx.x + 5] = wall_clock64(); } while (0)
+#define SGA_PROBE_END() do { SGA_STAMP_END(); if (a.clk && tid == 0) a.clk[6 * blockIdx.x + 5] = wall_clock64(); } while (0)
 #else
-#define SGA_PROBE_END() do { } while (0)
+#define SGA_PROBE_END() SGA_STAMP_END()
 #endif
 
   int bid = blockIdx.x;

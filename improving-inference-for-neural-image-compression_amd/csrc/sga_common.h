@@ -89,6 +89,8 @@ struct ConvArgs {
   unsigned long long* clk; // measurement only (SGA_CLOCK_PROBE=1, else null): per workgroup, shader-clock and 100 MHz
                            //   wall-clock ticks spent in the K loop -> the clock the chip sustains under this kernel
 #endif
+  unsigned long long* stamp;   // measurement only (sga_profile_graph_begin), else null: [0] = min over workgroups of the 100 MHz
+                           //   wall clock at entry, [1] = max at exit
   int reduce_batch;        // split-K reduce: issue the slab loads 8 at a time (main chain) or one by one
   int pair_phases;         // 4-phase launch whose whole grid is resident at once: walk the phases as 9,6,4,6 taps
   int bm;                  // rows per tile: 128 (default, 4 waves) or 256 (8 waves, big unsplit layers)

@@ -279,6 +279,15 @@ typedef struct sga_kernel_stat {
 } sga_kernel_stat;
 int sga_profile_begin(sga_handle* h);
 int sga_profile_end(sga_handle* h, sga_kernel_stat* out, int max_out, int* n_out);
+/* The same for ONE convolution kernel symbol inside the hipGraph replay that sga_run / sga_run_steps execute (what the
+ * headline number times).  HIP cannot time events recorded by graph nodes, so the first launch of `kernel_name` in the
+ * next captured iteration is handed a stamp pointer: its workgroups record the earliest entry and the latest exit on
+ * the 100 MHz wall clock; the graph is otherwise the production one (both streams), and every replay is followed by a
+ * stream synchronisation to read the pair.  sga_profile_graph_end returns launches, summed duration (first wave in to
+ * last wave out: what rocprofv3's kernel trace reports, without dispatch latency) and summed algorithmic flops, and
+ * drops the instrumented graph. */
+int sga_profile_graph_begin(sga_handle* h, const char* kernel_name);
+int sga_profile_graph_end(sga_handle* h, sga_kernel_stat* out);
 
 #ifdef __cplusplus
 }

@@ -24,8 +24,16 @@ except OSError:
 res = {"_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --roofline-only (eager), B=8 256x256 C=192; "
                   "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 averaged over the symbol's launches",
        "_commit": commit if len(sys.argv) < 5 else sys.argv[4]}
+# optional second pair of passes taken with SGA_NO_OVERLAP=1 (single stream: no hyper-branch kernel shares L2 / MALL with it)
+fe1, wr1 = ({}, {})
+if len(sys.argv) >= 7:
+    fe1, _ = load(sys.argv[5], "FETCH_SIZE")
+    wr1, _ = load(sys.argv[6], "WRITE_SIZE")
 for k in fe:
     res[k] = {"launches": nf[k], "fetch_bytes_per_launch": round(2 * fe[k] * 1024), "write_bytes_per_launch": round(wr.get(k, 0) * 1024),
               "hbm_bytes_per_launch": round((2 * fe[k] + wr.get(k, 0)) * 1024)}
+    if k in fe1:
+        res[k]["single_stream"] = {"fetch_bytes_per_launch": round(2 * fe1[k] * 1024),
+                                   "write_bytes_per_launch": round(wr1.get(k, 0) * 1024)}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
