@@ -602,8 +602,10 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
               *reinterpret_cast<f32x4*>(dst + (size_t)px[k] * a.out_cs + a.out_coff + n2 * TN * 32 + j * 32 + ec * 4) = v;
           }
       };
-      emit(a.out);                                   // u
-      __builtin_amdgcn_wave_barrier();
+      if (a.out) {                                   // u (null: the backward pass forms it as v / s)
+        emit(a.out);
+        __builtin_amdgcn_wave_barrier();
+      }
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
       if constexpr (PRO == GDN_PRO_CONV3) t[slot][kc] = *reinterpret_cast<const f32x4*>(tp + kr * R * TP + kc * CW * 4);
       else t[slot][kc] = ld4(a.src + ro + kc * CW * 4);
       if constexpr (MODE == GDN_IGDN_BWD) {
-        uu[slot][kc] = ld4(a.u + ro + kc * CW * 4);
+        uu[slot][kc] = ld4((a.v ? a.v : a.u) + ro + kc * CW * 4);
         ss[slot][kc] = ld4(a.s + ro + kc * CW * 4);
       }
     }
@@ -251,9 +251,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
     for (int kc = 0; kc < KC; ++kc) {
       f32x4 av;
       if constexpr (MODE == GDN_IGDN_BWD) {
-        av = t[slot][kc] * uu[slot][kc] / ss[slot][kc];      // operand of the contraction: g*u/s
+        f32x4 uv = uu[slot][kc];
+        if (a.v) {
+          // the forward pass stored v = u*s and s only (u is a third of the IGDN's write traffic): u = v/s, with
+          // v_rcp_f32 (1 ulp; the data-gradient is compared with float64 autograd at 1e-4)
+          f32x4 ri;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) ri[x] = __builtin_amdgcn_rcpf(ss[slot][kc][x]);
+          uv = uv * ri;
+          av = t[slot][kc] * uv * ri;                        // operand of the contraction: g*u/s
+        } else {
+          av = t[slot][kc] * uv / ss[slot][kc];
+        }
         e1[kr * KC + kc] = t[slot][kc] * ss[slot][kc];       // g*s
-        e2[kr * KC + kc] = uu[slot][kc];
+        e2[kr * KC + kc] = uv;
       } else {
         av = t[slot][kc] * t[slot][kc];
         e1[kr * KC + kc] = t[slot][kc];

@@ -114,6 +114,8 @@ struct sga_handle {
   bool fused_mse = true;           // distortion sums + gradient image in gs3.fwd's epilogue (SGA_FUSED_MSE=0: separate k_mse)
   bool fused_post = true;          // IGDN as the post-phase of the producing convolution launch (SGA_FUSED_POST=0: off)
   bool fused_gdn = true;           // gdn_fused.hip instead of the stand-alone GDN launches (SGA_FUSED_GDN=0: off)
+  bool keep_u = false;             // SGA_KEEP_U=1: the synthesis IGDNs also store their input u and the backward pass reads it
+                                   //   (bit-equal to the stand-alone launches); default: s and v only, u = v / s in igdn*.bwd
   int bm64_max = 256;              // 64-row tiles when the 128-row grid has at most this many blocks (SGA_BM64_MAX; 0 = off)
   bool bm256 = true;               // 256-row 8-wave tile for big unsplit f32 launches (SGA_BM256=0: off)
   bool bm256_split = true;         // ... and, split in two, for single-phase launches of 128 such tiles (SGA_BM256_SPLIT=0: off)
@@ -274,6 +276,7 @@ struct Deferred {
 // possible when the launch is an unsplit 256-row-tile one with all C = 192 channels in a tile.
 struct PostGdn {
   const float* gamma_w = nullptr; const float* beta = nullptr; float* s_out = nullptr; float* v_out = nullptr;
+  bool drop_u = false;       // in: the fused launch need not write u (the backward pass uses v / s)
   bool fused = false;        // out: the convolution launch did the IGDN as well
 };
 
@@ -360,6 +363,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
                   a.epi == EPI_BIAS && a.out_coff == 0 && a.out_cs == 192 && post->s_out && post->v_out;
     if (post->fused) {
       a.post = 1; a.post_w = post->gamma_w; a.post_beta = post->beta; a.post_s = post->s_out; a.post_v = post->v_out;
+      if (post->drop_u) a.out = nullptr;
       a.flops += 2.0 * a.B * a.Hout * a.Wout * 192.0 * 192.0;
     }
   }
@@ -762,7 +766,8 @@ void gdn_source(GdnArgs& g, const float* tensor, const Deferred* d) {
 // d (optional): u has not been assembled yet -- it is the sum of the producing convolution's split-K
 // slabs + bias; the kernel assembles it in its prologue and writes it to `u` as well.
 int gdn_fwd(sga_handle* h, const PackedConv& pc, const float* beta, float* u, int B, int Hh,
-            int Ww, float* s_out, float* out, bool inverse, hipStream_t st, const Deferred* d = nullptr) {
+            int Ww, float* s_out, float* out, bool inverse, hipStream_t st, const Deferred* d = nullptr,
+            bool write_u = true) {
   if (h->fused_gdn) {
     GdnArgs g;
     memset(&g, 0, sizeof(g));
@@ -770,7 +775,7 @@ int gdn_fwd(sga_handle* h, const PackedConv& pc, const float* beta, float* u, in
     g.M = (long long)B * Hh * Ww;
     gdn_source(g, u, d);
     g.w = pc.w; g.beta = beta; g.out = out; g.s_out_p = s_out;
-    g.u_out = (d && d->active) ? u : nullptr;
+    g.u_out = (d && d->active && write_u) ? u : nullptr;
     g.flops = 2.0 * B * Hh * Ww * (double)pc.Kc * pc.N;
     return gdn_launch(h, g, st);
   }
@@ -787,9 +792,11 @@ int gdn_fwd(sga_handle* h, const PackedConv& pc, const float* beta, float* u, in
 // IGDN backward: g_u = g_v * s + u * (gamma . (g_v * u / s)).  g_v is a tensor, or (d) the un-reduced
 // split-K slabs of the convolution that produces it, or (gpad != null) the 5x5/2 convolution of the
 // zero-bordered 3-channel gradient image with the C->3 layer's kernel, computed in the same launch.
+// `v` (optional, fused kernel only): the IGDN's output; when given, u is not read but formed as v / s.
 int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float* u, const float* s,
              int B, int Hh, int Ww, float* g_u, hipStream_t st, const Deferred* d = nullptr,
-             const float* gpad = nullptr, const PackedConv* pc3 = nullptr, int Hp = 0, int Wp = 0) {
+             const float* gpad = nullptr, const PackedConv* pc3 = nullptr, int Hp = 0, int Wp = 0,
+             const float* v = nullptr) {
   if (h->fused_gdn) {
     GdnArgs g;
     memset(&g, 0, sizeof(g));
@@ -797,7 +804,7 @@ int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float*
     g.M = (long long)B * Hh * Ww;
     gdn_source(g, g_v, d);
     if (gpad) { g.pad = gpad; g.wc = pc3->w; g.Hg = Hh; g.Wg = Ww; g.Hp = Hp; g.Wp = Wp; }
-    g.w = pc.w; g.u = u; g.s = s; g.out = g_u;
+    g.w = pc.w; g.u = u; g.s = s; g.out = g_u; g.v = v;
     g.flops = 2.0 * B * Hh * Ww * (double)pc.Kc * pc.N + (gpad ? 2.0 * B * Hh * Ww * 75.0 * pc.N : 0.0);
     return gdn_launch(h, g, st);
   }
@@ -962,10 +969,14 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   // Layers whose tile grid under-fills the chip run split-K; their partial slabs are summed (+ bias)
   // by the IGDN kernel that follows instead of by a reduce launch (fused_gdn).
   const bool fz = h->fused_gdn;
+  // u is needed again only by the IGDN data-gradient, which can form it as v / s: with the tile kernels in use the
+  // forward pass stores s and v only (gs2.fwd + IGDN writes 201 instead of 302 MB at cfg 2)
+  const bool drop_u = fz && with_grad && !h->keep_u;
   for (int L = 0; L < 3; ++L) {
     Deferred d;
     PostGdn pg;
     pg.gamma_w = h->gs_gdn_f[L].w; pg.beta = h->gs_beta[L]; pg.s_out = h->s[L].p; pg.v_out = h->v[L].p;
+    pg.drop_u = drop_u;
     SGACHK(tick());
     h->cur_tag = kFwd[L];
     SGACHK(deconv_fwd(h, h->gs_f[L], h->gs_bias[L], cur, B, hh, ww, h->u[L].p, EPI_BIAS, st, fz ? &d : nullptr,
@@ -974,7 +985,7 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
     if (!pg.fused) {           // otherwise the IGDN ran as the post-phase of the convolution launch
       SGACHK(tick());
       h->cur_tag = kIgdn[L];
-      SGACHK(gdn_fwd(h, h->gs_gdn_f[L], h->gs_beta[L], h->u[L].p, B, hh, ww, h->s[L].p, h->v[L].p, true, st, &d));
+      SGACHK(gdn_fwd(h, h->gs_gdn_f[L], h->gs_beta[L], h->u[L].p, B, hh, ww, h->s[L].p, h->v[L].p, true, st, &d, !drop_u));
     }
     cur = h->v[L].p;
   }
@@ -1006,9 +1017,10 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
     h->cur_tag = kIgdnB[L];
     if (L == 2 && conv3_fused)
       SGACHK(igdn_bwd(h, h->gs_gdn_b[L], nullptr, h->u[L].p, h->s[L].p, B, hh, ww, h->gB.p, st, nullptr,
-                      h->gpad.p, &h->gs_b[3], g.Hp, g.Wp));
+                      h->gpad.p, &h->gs_b[3], g.Hp, g.Wp, drop_u ? h->v[L].p : nullptr));
     else
-      SGACHK(igdn_bwd(h, h->gs_gdn_b[L], h->gA.p, h->u[L].p, h->s[L].p, B, hh, ww, h->gB.p, st, &d));
+      SGACHK(igdn_bwd(h, h->gs_gdn_b[L], h->gA.p, h->u[L].p, h->s[L].p, B, hh, ww, h->gB.p, st, &d, nullptr, nullptr, 0, 0,
+                      drop_u ? h->v[L].p : nullptr));
     float* dst = (L == 0) ? h->g_yt_dist.p : h->gA.p;
     SGACHK(tick());
     h->cur_tag = kBwd[L];
@@ -1375,6 +1387,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   // gdn_fused.hip has instances for C / 32 in {2, 4, 6, 8}; wider models (num_filters = 320, 384, ...) take the generic
   // gather-GEMM GDN with an ordinary split-K reduce (conv_mfma.hip tiles any channel count)
   if (C / 32 != 2 && C / 32 != 4 && C / 32 != 6 && C / 32 != 8) h->fused_gdn = false;
+  env = getenv("SGA_KEEP_U");
+  h->keep_u = env && env[0] == '1';
   env = getenv("SGA_FUSED_POST");
   h->fused_post = !(env && env[0] == '0');
   env = getenv("SGA_PLAN_TILES");

@@ -131,6 +131,7 @@ struct GdnArgs {
   const float* w;          // gamma, [C][C]: row = output channel, K contiguous (pack_gdn)
   const float* beta;       // forward
   const float* u; const float* s;     // backward: pre-IGDN activation and sqrt(n) of the forward pass
+  const float* v;                     // backward, when the forward pass did not store u: v = u*s (then u = v/s; `u` unused)
   float* out;              // forward: v;  backward: g_u
   float* s_out_p;          // forward IGDN: sqrt(n) (or null)
   float* u_out;            // forward: T written back (needed when T was assembled here), or null

@@ -17,20 +17,27 @@ import sga_amd  # noqa: E402
 
 
 def _pair(C, B, H, W):
+    """fused: the tile kernels / POST phase with SGA_KEEP_U=1 (the IGDN also stores its input u and the data-gradient
+    reads it: the arithmetic of the stand-alone launches); legacy: SGA_FUSED_GDN=0; default: what ships (s and v
+    stored, u = v / s by v_rcp_f32 in igdn*.bwd -- not bit-equal by construction, compared to 1e-5 below and with
+    the oracle everywhere else)."""
     from sga_amd.codec import SGACodec
     w = sga_amd.make_synthetic_weights(C, seed=0)
-    old = os.environ.get("SGA_FUSED_GDN")
+    old = {k: os.environ.get(k) for k in ("SGA_FUSED_GDN", "SGA_KEEP_U")}
     try:
-        os.environ["SGA_FUSED_GDN"] = "1"
+        os.environ["SGA_FUSED_GDN"] = "1"; os.environ["SGA_KEEP_U"] = "1"
         fused = SGACodec(w, C, B, H, W)
         os.environ["SGA_FUSED_GDN"] = "0"
         legacy = SGACodec(w, C, B, H, W)
+        os.environ.pop("SGA_FUSED_GDN"); os.environ.pop("SGA_KEEP_U")
+        default = SGACodec(w, C, B, H, W)
     finally:
-        if old is None:
-            os.environ.pop("SGA_FUSED_GDN", None)
-        else:
-            os.environ["SGA_FUSED_GDN"] = old
-    return fused, legacy
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return fused, legacy, default
 
 
 # shapes: every tile shape of gdn_fused.hip (general / 32-row "small", C = 64..256), ragged sizes,
@@ -43,7 +50,7 @@ SHAPES = [(64, 2, 64, 64), (64, 1, 50, 70), (128, 1, 37, 41), (192, 2, 64, 48), 
 
 @pytest.mark.parametrize("C,B,H,W", SHAPES)
 def test_fused_equals_unfused_bitwise(C, B, H, W):
-    fused, legacy = _pair(C, B, H, W)
+    fused, legacy, default = _pair(C, B, H, W)
     x = np.random.RandomState(C + H).rand(B, H, W, 3).astype(np.float32)
     ya, za = fused.encode(x)
     yb, zb = legacy.encode(x)
@@ -53,12 +60,17 @@ def test_fused_equals_unfused_bitwise(C, B, H, W):
     assert torch.equal(ra["gy"], rb["gy"]) and torch.equal(ra["gz"], rb["gz"])
     assert ra["rd_loss"] == rb["rd_loss"] and ra["train_mse"] == rb["train_mse"]
     assert float(ra["gy"].abs().max()) > 0
+    # what ships: the forward pass stores s and v, the IGDN data-gradient forms u = v / s
+    rc = default.step_grads(x, ya, za, 0.4, 0.01, seed=3, it=5)
+    assert rc["rd_loss"] == ra["rd_loss"] and torch.equal(rc["gz"], ra["gz"])          # forward and hyper branch untouched
+    err = float((rc["gy"] - ra["gy"]).abs().max() / ra["gy"].abs().max())
+    assert 0 < err < 1e-5, err
     its = 12 if H * W > 40000 else 30
     a = fused.run(x, 0.01, its=its, seed=1)
     b = legacy.run(x, 0.01, its=its, seed=1)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert torch.equal(a[2][:, [0, 1, 4, 5, 6]], b[2][:, [0, 1, 4, 5, 6]])
-    fused.close(); legacy.close()
+    fused.close(); legacy.close(); default.close()
 
 
 def _codec_env(name, value, *args):
