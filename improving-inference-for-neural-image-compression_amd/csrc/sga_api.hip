@@ -123,6 +123,10 @@ struct sga_handle {
   int dbg_it = -1;                 // iteration being enqueued (SGA_DEBUG_DUMP)
   hipEvent_t ev_fork_cap = nullptr, ev_join_cap = nullptr;   // while `st` is being captured
   bool overlap = true;             // SGA_NO_OVERLAP=1 disables
+  bool side_masked = false;        // sB was created with a CU mask (hipExtStreamCreateWithCUMask)
+  int branch_only = 0;             // rd_forward_backward: 0 both branches (fork / join), 1 synthesis branch only, 2 hyper branch only
+  hipGraphExec_t graph_main = nullptr;   // hybrid replay: the synthesis branch of one iteration (the hyper branch is launched eagerly on the masked stream)
+  int gmain_B = 0, gmain_H = 0, gmain_W = 0;
   ImgSums* sums = nullptr;
   StepCtx* ctx = nullptr;
   int* img_ids = nullptr;        // [max_batch] position of each image in its reference batch (sga_set_image_ids)
@@ -1042,6 +1046,16 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
                         hipStream_t st, bool density = false, bool do_synth = true) {
   // bf16x3 mode runs single-stream: with the hyper branch on a second stream its results were not
   // reproducible run to run (the f32 mode is, and is the default)
+  if (h->branch_only == 1) {       // hybrid replay: this call enqueues one branch only (sga_run_steps orders them)
+    h->cur_part = &h->part;
+    return synth_branch(h, g, x, with_grad, st);
+  }
+  if (h->branch_only == 2) {
+    h->cur_part = &h->partB;
+    const int rc = hyper_branch(h, g, with_grad, st, density);
+    h->cur_part = &h->part;
+    return rc;
+  }
   const bool fork = h->overlap && !h->x3 && !h->profiling && do_synth;
   if (!fork) {
     h->cur_part = &h->part;
@@ -1129,6 +1143,7 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
 
 void free_all(sga_handle* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  if (h->graph_main) (void)hipGraphExecDestroy(h->graph_main);
   for (int k = 0; k < 2; ++k) if (h->bb_graph[k]) (void)hipGraphExecDestroy(h->bb_graph[k]);
   for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1351,7 +1366,23 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     (void)lo; (void)hi;
     if (const char* pr = getenv("SGA_SIDE_PRIORITY")) prio = atoi(pr);   // experiments only
     const unsigned evflags = hipEventDisableTiming;
-    if (hipStreamCreateWithPriority(&h->sB, hipStreamNonBlocking, prio) != hipSuccess ||
+    // Experiment: SGA_SIDE_CU_MASK=<hex words, lowest first, comma separated> confines the hyper branch's
+    // stream to the CUs whose bits are set (hipExtStreamCreateWithCUMask).  A mask belongs to a stream, and kernel
+    // nodes of a replayed hipGraph do not inherit it, so this only acts on eager launches (SGA_NO_GRAPH=1).
+    bool masked = false;
+    if (const char* cm = getenv("SGA_SIDE_CU_MASK")) {
+      std::vector<uint32_t> words;
+      for (const char* q = cm; *q;) {
+        char* end = nullptr;
+        words.push_back((uint32_t)strtoul(q, &end, 16));
+        if (end == q) break;
+        q = *end == ',' ? end + 1 : end;
+      }
+      masked = !words.empty() && hipExtStreamCreateWithCUMask(&h->sB, (uint32_t)words.size(), words.data()) == hipSuccess;
+      if (!masked) (void)hipGetLastError();
+    }
+    h->side_masked = masked;
+    if ((!masked && hipStreamCreateWithPriority(&h->sB, hipStreamNonBlocking, prio) != hipSuccess) ||
         hipEventCreateWithFlags(&h->ev_fork, evflags) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, evflags) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork_cap, evflags) != hipSuccess ||
@@ -1615,6 +1646,56 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
     }
     return SGA_OK;
   };
+
+  // ---- hybrid replay (side stream confined to a CU subset) ------------------------------------------------------
+  // A CU mask is a property of a stream's hardware queue; the kernel nodes of a replayed hipGraph run on the
+  // runtime's own streams and do not inherit it.  So only the MAIN chain (the synthesis branch, 20 launches) is a
+  // captured graph; the hyper branch is launched eagerly on the masked stream every iteration, and the two meet
+  // at the boundary kernel through a pair of events:
+  //   sB: wait(ev_iter: relaxed latents of this iteration exist) . hyper branch . record(ev_side)
+  //   st: graph(main chain) . wait(ev_side) . boundary kernel (Adam + next relaxation) . record(ev_iter)
+  // Same kernels, same arguments, same order per stream as the two-stream graph: results are bit-identical.
+  if (h->side_masked && h->use_graph && !h->profiling && fb && h->overlap && !h->x3) {
+    if (!h->graph_main || h->gmain_B != B || h->gmain_H != H || h->gmain_W != W) {
+      if (h->graph_main) { (void)hipGraphExecDestroy(h->graph_main); h->graph_main = nullptr; }
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        h->branch_only = 1;
+        const int rc = rd_forward_backward(h, g, h->xin.p, true, st);
+        h->branch_only = 0;
+        const hipError_t ec = hipStreamEndCapture(st, &graph);
+        if (rc == SGA_OK && ec == hipSuccess && graph &&
+            hipGraphInstantiate(&h->graph_main, graph, nullptr, nullptr, 0) == hipSuccess) {
+          h->gmain_B = B; h->gmain_H = H; h->gmain_W = W;
+        } else {
+          h->graph_main = nullptr;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+      }
+      (void)hipGetLastError();
+    }
+    if (h->graph_main) {
+      HIPCHK(h, hipEventRecord(h->ev_fork, st));                  // ev_iter: the relaxed latents of iteration run_it exist
+      for (int k = 0; k < n; ++k) {
+        static const bool skip_side = getenv("SGA_SKIP_SIDE") != nullptr;      // timing experiment only: results are wrong
+        HIPCHK(h, hipStreamWaitEvent(h->sB, h->ev_fork, 0));
+        h->branch_only = 2;
+        const int rs = skip_side ? SGA_OK : rd_forward_backward(h, g, h->xin.p, true, h->sB);
+        h->branch_only = 0;
+        SGACHK(rs);
+        HIPCHK(h, hipEventRecord(h->ev_join, h->sB));
+        HIPCHK(h, hipGraphLaunch(h->graph_main, st));
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+        HIPCHK(h, launch_step_boundary(h->y.p, h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, h->my.p, h->vy.p, h->yt.p, ny,
+                                       h->z.p, h->g_zt_hs.p, h->g_zt_eb.p, h->dzt.p, h->mz.p, h->vz.p, h->zt.p, nz,
+                                       h->ctx, h->relax, h->img_ids, B, H, W, h->sums, h->trace.p, h->Ttab.p,
+                                       h->lrtab.p, h->ticket, st));
+        HIPCHK(h, hipEventRecord(h->ev_fork, st));
+      }
+      h->run_it += n;
+      return SGA_OK;
+    }
+  }
 
   bool graphed = false;
   if (h->use_graph && !h->profiling) {
