@@ -29,8 +29,12 @@ TOL_BPP, TOL_PSNR = 1e-3, 0.01          # north_star tolerance
 # the complete two-stage bits-back run of bb_sga.py:199-276 (C = 64, 2 x 64^2, 2000 + 2000 iterations, 32 seeds)
 # a ragged set (3 x 50 x 70: latents 4 x 5 and 1 x 2, every crop live in all 2000 steps) and one at cfg 4's rate
 # point (lambda = 0.08)
+# ... the small set again against the FLOAT64 oracle (the control of tests/test_oracle.py: float32-vs-float64 oracle runs
+# differ from each other exactly as the HIP path differs from either), and -- when present -- the BENCHMARKED geometry
+# (cfg 2: B = 8, 256^2, C = 192: POST / 256-row LDS-DMA / split gs2.bwd kernels and the two-stream graph over 2000 steps)
 @pytest.mark.parametrize("golden", ["full_run_oracle.json", "full_run_oracle_c192.json", "full_run_oracle_bb.json",
-                                    "full_run_oracle_ragged.json", "full_run_oracle_hirate.json"])
+                                    "full_run_oracle_ragged.json", "full_run_oracle_hirate.json",
+                                    "full_run_oracle_f64.json", "full_run_oracle_cfg2.json"])
 def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir, golden):
     _acceptance(gpu_out_dir, golden, "f32", "")
 
@@ -42,7 +46,10 @@ def test_full_run_bf16x3_mode_within_north_star_tolerance(gpu_out_dir):
 
 def _acceptance(gpu_out_dir, golden, precision, tag):
     from sga_amd.codec import SGACodec, metrics_to_dict
-    with open(os.path.join(ROOT, "tests", "golden", golden)) as f:
+    path = os.path.join(ROOT, "tests", "golden", golden)
+    if not os.path.exists(path):
+        pytest.skip(golden + " not generated yet (tests/tools/make_golden_full_run.py)")
+    with open(path) as f:
         gold = json.load(f)
     cfg = gold["config"]
     C, B, H, W = cfg["C"], cfg["B"], cfg["H"], cfg["W"]
@@ -101,4 +108,7 @@ def _acceptance(gpu_out_dir, golden, precision, tag):
     assert (np.abs(d_bpp) <= 5 * sig_b[None, :] + 1e-4).all(), rep
     assert (np.abs(d_psnr) <= 5 * sig_p[None, :] + 1e-3).all(), rep
     ratio = np.array(rep["hip_seed_std_bpp"]) / np.array(spread["est_bpp_std_per_image"])
-    assert (ratio > 0.5).all() and (ratio < 2.0).all(), rep
+    # (a standard deviation estimated from k seeds has a relative error of ~ 1 / sqrt(2 (k - 1)): wider bounds for the
+    # 5-seed set at the benchmarked geometry)
+    lo, hi = (0.5, 2.0) if len(gold["runs"]) >= 16 else (0.3, 3.3)
+    assert (ratio > lo).all() and (ratio < hi).all(), rep

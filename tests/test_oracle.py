@@ -370,3 +370,40 @@ def test_architecture_matches_reference_executed_layer_table(C):
     # the importer reads `kernel` (not `kernel_rdft`) exactly where nn_models.py passes kernel_parameterizer=None
     assert all("kernel_parameterizer" in l and l["kernel_parameterizer"] is None for l in ref["hyper_synthesis"])
     assert not any("kernel_parameterizer" in l for t in ("analysis", "synthesis", "hyper_analysis") for l in ref[t])
+
+
+def test_float32_vs_float64_oracle_control_for_the_statistical_acceptance_criterion():
+    """CONTROL EXPERIMENT for tests/test_gpu_acceptance.py.  The GPU test asserts the north-star tolerance
+    (1e-3 bpp, 0.01 dB) on MEANS over images x seeds because a 2000-step run amplifies last-bit differences.  Here the
+    same claim is tested without any GPU: the small golden set's inputs and Philox seeds went through the oracle twice,
+    in float32 (`full_run_oracle.json`) and in float64 (`full_run_oracle_f64.json`; generator
+    tests/tools/make_golden_full_run.py, GOLDEN=f64) -- identical noise, identical f32-pinned Adam, only the rounding of
+    the graph's arithmetic differs.  If single runs of THAT pair already differ by more than 1e-3 bpp, a per-run bound
+    is not a property of the reference against itself, and the spread the GPU test tolerates is the reference's own."""
+    with open(os.path.join(GOLDEN, "full_run_oracle.json")) as f:
+        a = json.load(f)
+    with open(os.path.join(GOLDEN, "full_run_oracle_f64.json")) as f:
+        b = json.load(f)
+    ca, cb = dict(a["config"]), dict(b["config"])
+    assert cb.pop("dtype") == "float64" and "dtype" not in ca
+    assert ca == cb                                              # same inputs, weights, seeds, lambda, iterations, bound
+    A, B = {r["seed"]: r for r in a["runs"]}, {r["seed"]: r for r in b["runs"]}
+    assert sorted(A) == sorted(B) and len(A) >= 32
+    d_bpp = np.array([np.array(B[s]["est_bpp"]) - np.array(A[s]["est_bpp"]) for s in sorted(A)])      # [seed, image]
+    d_psnr = np.array([np.array(B[s]["psnr"]) - np.array(A[s]["psnr"]) for s in sorted(A)])
+    n = d_bpp.size
+    mean, sem, std = d_bpp.mean(), d_bpp.std(ddof=1) / np.sqrt(n), d_bpp.std(ddof=1)
+    frac = float((np.abs(d_bpp) <= 1e-3).mean())
+    # measured: mean +2.5e-4 +- 1.1e-4, std 1.25e-3, max 3.3e-3, 61 % of single runs within 1e-3 bpp, all within 0.01 dB
+    assert np.abs(d_bpp).max() > 2e-3 and frac < 0.8             # single runs of the reference against itself break 1e-3
+    assert 0.5e-3 < std < 2.5e-3
+    assert abs(mean) <= 1e-3 and abs(d_psnr.mean()) <= 0.01      # the means keep the north-star tolerance ...
+    assert abs(mean) <= 4 * sem                                  # ... and are compatible with zero offset
+    assert np.abs(d_psnr).max() <= 0.01
+    # the HIP path's committed acceptance report against the same float32 golden set has the same statistics
+    rep_path = os.path.join(os.path.dirname(GOLDEN), "..", "profiles", "r02_acceptance_full_run.json")
+    with open(rep_path) as f:
+        rep = json.load(f)
+    hip_std = rep["sem_d_bpp"] * np.sqrt(rep["n"])
+    assert 0.5 < hip_std / std < 2.0 and abs(rep["frac_within_1e3_bpp"] - frac) < 0.25
+    assert abs(rep["max_abs_d_bpp"] / np.abs(d_bpp).max() - 1) < 0.5
