@@ -74,7 +74,7 @@ constexpr bool glds_instance(int TM, int TN, int WM, int WN, int PRO, bool SMALL
   // main chain's way: the iteration measured 1868 against 1827 us)
   return !X3 && !SMALLC && PRO == PRO_NONE &&
          ((POST == 0 && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2) ||
-          (POST == 0 && TM == 2 && TN == 4 && WM == 4 && WN == 2));
+          (TM == 2 && TN == 4 && WM == 4 && WN == 2));
 }
 
 // 16 bytes per lane, global memory -> LDS at `lds_dst` (wave-uniform) + lane * 16, no registers in between.
@@ -87,10 +87,13 @@ __device__ __forceinline__ void dma16_to_lds(const float* src, float* lds_dst) {
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// POST = 1 (256-row tile, BN = C = 192 only): the IGDN that follows the transposed convolution
+// POST = 1 (256-row tile, BN = C = 192 or 256): the IGDN that follows the transposed convolution
 // (nn_models.py:48-59) runs as a post-phase of the SAME launch, on the tile while it is on chip:
 // u = acc + bias goes to LDS, n = gamma . u^2 is a second MFMA contraction out of LDS, s = sqrt(n + beta),
-// v = u * s; u, s and v leave in whole 16-byte row pieces.  See the block after the K loop.
+// v = u * s; (u,) s and v leave in whole 16-byte row pieces.  See the block after the K loop.
+// The tile goes through LDS in parts of post_rows(BN) rows, sized so that a part + two gamma K-chunks fit:
+// C = 192: 128 x 196 + 2 x 192 x 36 floats = 152 KB;  C = 256 (README.md:58-60, cfg 4): 64 x 260 + 2 x 256 x 36 = 137 KB.
+constexpr int post_rows(int BN) { return BN <= 192 ? 128 : 64; }
 template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3, int POST = 0>
 __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = WM * WN * 64;
@@ -104,10 +107,11 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   constexpr bool GLDS = glds_instance(TM, TN, WM, WN, PRO, SMALLC, X3, POST);
   constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (GLDS ? 2 * (BM + BN) * 32 : (BM + BN) * LDK);
   constexpr int EPI_FLOATS = WM * WN * 32 * CPITCH;
-  constexpr int POST_FLOATS = POST ? (128 * (BN + 4) + 2 * BN * LDK) : 0;
+  constexpr int POST_FLOATS = POST ? (post_rows(BN) * (BN + 4) + 2 * BN * LDK) : 0;
   constexpr int LDS_FLOATS0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   constexpr int LDS_FLOATS = LDS_FLOATS0 > POST_FLOATS ? LDS_FLOATS0 : POST_FLOATS;
-  static_assert(!POST || (BM == 256 && BN == 192 && NT == 512 && !X3 && !SMALLC && PRO == PRO_NONE), "post-phase instance");
+  static_assert(!POST || (BM == 256 && (BN == 192 || BN == 256) && NT == 512 && TM == 2 && !X3 && !SMALLC && PRO == PRO_NONE),
+                "post-phase instance");
   constexpr int PBX = X3 ? (BN * 12) / NT : 1;     // 16-byte pieces of the 3-plane weight tile per thread
   static_assert(!X3 || (BN * 12) % NT == 0, "x3 loader mismatch");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -519,19 +523,23 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
   const int half = lane >> 5, col = lane & 31;
   if constexpr (POST) {
-    // ---- fused IGDN (two halves of 128 tile rows; all 8 waves multiply, one barrier per K-step) ----
+    // ---- fused IGDN (the tile in parts of HR rows; all 8 waves multiply, one barrier per K-step) ----
     constexpr int C = BN, TP = C + 4;
-    float* const Tt = smem;                          // [128][TP]: u of the current half
-    float* const Bq = smem + 128 * TP;               // [2][C][LDK]: gamma K-chunks, double-buffered
-    const int m4 = wid >> 1, n2 = wid & 1;           // post-phase wave grid 4 (rows) x 2 (cols): 32 x 96 each
-    float bias_c[TN], beta_c[TN];                    // per-lane columns: before any store is in flight
+    constexpr int HR = post_rows(BN), NPART = BM / HR;   // 128 x 2 (C = 192) or 64 x 4 (C = 256)
+    constexpr int PM = HR / 32, PN = 8 / PM;             // post-phase wave grid: PM (rows) x PN (cols) blocks of 32 x (PTN * 32)
+    constexpr int PTN = (C / 32) / PN;                   // 3 (32 x 96 per wave) or 2 (32 x 64)
+    constexpr int OW = HR / 64;                          // main-loop wave rows (64 tile rows each) per part
+    static_assert(PM * PN == 8 && PTN * PN * 32 == C && OW * 64 == HR, "post-phase wave grid");
+    float* const Tt = smem;                          // [HR][TP]: u of the current part
+    float* const Bq = smem + HR * TP;                // [2][C][LDK]: gamma K-chunks, double-buffered
+    const int m4 = wid / PN, n2 = wid % PN;
+    float bias_c[TN], beta_c[PTN];                   // per-lane columns: before any store is in flight
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      bias_c[tn] = a.bias ? a.bias[(wn * TN + tn) * 32 + col] : 0.f;
-      beta_c[tn] = a.post_beta[(n2 * TN + tn) * 32 + col];
-    }
+    for (int tn = 0; tn < TN; ++tn) bias_c[tn] = a.bias ? a.bias[(wn * TN + tn) * 32 + col] : 0.f;
+#pragma unroll
+    for (int tn = 0; tn < PTN; ++tn) beta_c[tn] = a.post_beta[(n2 * PTN + tn) * 32 + col];
     // gamma chunk loader: C rows x 32 floats = C*8 float4 over 512 threads
-    constexpr int QB = C * 8 / NT;                   // 3
+    constexpr int QB = C * 8 / NT;                   // 3 or 4
     f32x4 rq[QB];
     auto load_q = [&](int kc) {
 #pragma unroll
@@ -544,24 +552,24 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
     };
     lds_barrier();                                   // main-loop LDS is dead from here on
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NPART; ++h) {
       load_q(0);
-      if ((wm >> 1) == h) {                          // the 4 waves that own these 128 rows: u = acc + bias
+      if (wm / OW == h) {                            // the waves that own these HR rows: u = acc + bias
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
-              Tt[((wm & 1) * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * TP + (wn * TN + tn) * 32 + col] =
+              Tt[((wm % OW) * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * TP + (wn * TN + tn) * 32 + col] =
                   acc[tm][tn][reg] + bias_c[tn];
       }
       store_q(0);
       load_q(1);
       lds_barrier();
-      f32x16 acc2[TN];
+      f32x16 acc2[PTN];
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
+      for (int tn = 0; tn < PTN; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[tn][r] = 0.f;
 #pragma unroll
@@ -573,33 +581,33 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
         for (int q = 0; q < 4; ++q) {
           f32x4 af = *reinterpret_cast<const f32x4*>(&Tt[(m4 * 32 + col) * TP + kc * 32 + q * 8 + koff]);
           af = af * af;
-          f32x4 bf2[TN];
+          f32x4 bf2[PTN];
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-            bf2[tn] = *reinterpret_cast<const f32x4*>(&Bs2[((n2 * TN + tn) * 32 + col) * LDK + q * 8 + koff]);
+          for (int tn = 0; tn < PTN; ++tn)
+            bf2[tn] = *reinterpret_cast<const f32x4*>(&Bs2[((n2 * PTN + tn) * 32 + col) * LDK + q * 8 + koff]);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
+            for (int tn = 0; tn < PTN; ++tn)
               acc2[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r], bf2[tn][r], acc2[tn], 0, 0, 0);
         }
         lds_barrier();
       }
-      // ---- epilogue of the half: this wave's private 32 x 96 block of the tile -------------------
-      float* const cb = Tt + (m4 * 32 + 4 * half) * TP + n2 * TN * 32 + col;     // C-layout base
+      // ---- epilogue of the part: this wave's private 32 x (PTN * 32) block of the tile ---------------
+      float* const cb = Tt + (m4 * 32 + 4 * half) * TP + n2 * PTN * 32 + col;     // C-layout base
       const int er = lane >> 3, ec = lane & 7;                                    // row-major: 8 lanes per row
-      const float* const rb0 = Tt + (m4 * 32 + er) * TP + n2 * TN * 32 + ec * 4;
+      const float* const rb0 = Tt + (m4 * 32 + er) * TP + n2 * PTN * 32 + ec * 4;
       long long px[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) px[k] = rowpix[h * 128 + m4 * 32 + er + 8 * k];
+      for (int k = 0; k < 4; ++k) px[k] = rowpix[h * HR + m4 * 32 + er + 8 * k];
       auto emit = [&](float* dst) {                  // the block, row-major, 16 bytes per lane
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-          for (int j = 0; j < 3; ++j) {
+          for (int j = 0; j < PTN; ++j) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(rb0 + k * 8 * TP + j * 32);
             if (px[k] >= 0)
-              *reinterpret_cast<f32x4*>(dst + (size_t)px[k] * a.out_cs + a.out_coff + n2 * TN * 32 + j * 32 + ec * 4) = v;
+              *reinterpret_cast<f32x4*>(dst + (size_t)px[k] * a.out_cs + a.out_coff + n2 * PTN * 32 + j * 32 + ec * 4) = v;
           }
       };
       if (a.out) {                                   // u (null: the backward pass forms it as v / s)
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
         __builtin_amdgcn_wave_barrier();
       }
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
+      for (int tn = 0; tn < PTN; ++tn)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           float* e = cb + ((reg & 3) + 8 * (reg >> 2)) * TP + tn * 32;
@@ -617,13 +625,13 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
       emit(a.post_v);                                // v
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
+      for (int tn = 0; tn < PTN; ++tn)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
           cb[((reg & 3) + 8 * (reg >> 2)) * TP + tn * 32] = sqrtf(acc2[tn][reg] + beta_c[tn]);   // s (recomputed: registers are short)
       __builtin_amdgcn_wave_barrier();
       emit(a.post_s);                                // s
-      lds_barrier();                                 // the tile is rewritten by the next half
+      lds_barrier();                                 // the tile is rewritten by the next part
     }
     SGA_PROBE_END();
     return;
@@ -778,7 +786,7 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr bool GLDS = glds_instance(TM, TN, WM, WN, PRO, SMALLC, X3, POST);
   constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (GLDS ? 2 * (BM + BN) * 32 : (BM + BN) * LDK);
   constexpr int EPI_FLOATS = WM * WN * 32 * (TN * 32 + 4);
-  constexpr int POST_FLOATS = POST ? (128 * (BN + 4) + 2 * BN * LDK) : 0;
+  constexpr int POST_FLOATS = POST ? (post_rows(BN) * (BN + 4) + 2 * BN * LDK) : 0;
   constexpr int F0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   const size_t lds = (size_t)(F0 > POST_FLOATS ? F0 : POST_FLOATS) * sizeof(float) + BM * sizeof(long long);
   // once per (instance, device): a process may drive several GPUs, and handles may live on several threads
@@ -886,7 +894,12 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
       return launch_pro<2, 3, 2, 2>(a, stream);
     case 256:
       if (a.bm == 256) {      // C = 256: 8 waves, 256 x 256 tile, LDS-DMA loop
-        if (a.smallc || a.pro != PRO_NONE || a.x3 || a.post) return (int)hipErrorInvalidValue;
+        if (a.smallc || a.pro != PRO_NONE || a.x3) return (int)hipErrorInvalidValue;
+        if (a.post) {
+          if (a.ksplit > 1 || a.epi != EPI_BIAS || a.Cout != 256 || a.out_coff != 0 || a.out_cs != 256)
+            return (int)hipErrorInvalidValue;
+          return launch_inst<2, 4, 4, 2, PRO_NONE, false, false, 1>(a, stream);
+        }
         return launch_inst<2, 4, 4, 2, PRO_NONE, false>(a, stream);
       }
       return launch_pro<2, 4, 2, 2>(a, stream);

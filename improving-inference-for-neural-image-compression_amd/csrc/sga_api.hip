@@ -337,7 +337,11 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     const long long n128 = (long long)a.nphase * cdiv(rows, 128) * a.ntiles_n;
     const long long n256 = (long long)a.nphase * cdiv(rows, 256) * a.ntiles_n;
     const double bonus = 1.04;      // the LDS-DMA loop against the register-staged 128-row one
-    double e256 = grid_efficiency(256, n256);
+    // unsplit, the 256-row launch can also do the IGDN that follows (POST): saves that launch, measured at the
+    // Tecnick shape (profiles/r03_configs.txt)
+    const bool with_post = post && h->fused_post && a.Cout == 256 && a.Npad == 256 && a.epi == EPI_BIAS &&
+                           a.out_coff == 0 && a.out_cs == 256 && post->s_out && post->v_out;
+    double e256 = grid_efficiency(256, n256) * (with_post ? 1.12 : 1.0);
     if (h->bm256_split && a.nphase == 1) e256 = std::max(e256, best_split(256, n256, nullptr));
     if (n128 >= 512 && e256 * bonus >= best_split(128, n128, nullptr)) {
       a.bm = 256;
@@ -363,12 +367,12 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   }
   if (defer && a.epi != EPI_BIAS) return SGA_ERR_BAD_ARG;   // the consumer applies "+ bias" only
   if (post) {
-    post->fused = h->fused_post && a.bm == 256 && a.ksplit <= 1 && a.Cout == 192 && a.Npad == 192 &&
-                  a.epi == EPI_BIAS && a.out_coff == 0 && a.out_cs == 192 && post->s_out && post->v_out;
+    post->fused = h->fused_post && a.bm == 256 && a.ksplit <= 1 && (a.Cout == 192 || a.Cout == 256) && a.Npad == a.Cout &&
+                  a.epi == EPI_BIAS && a.out_coff == 0 && a.out_cs == a.Cout && post->s_out && post->v_out;
     if (post->fused) {
       a.post = 1; a.post_w = post->gamma_w; a.post_beta = post->beta; a.post_s = post->s_out; a.post_v = post->v_out;
       if (post->drop_u) a.out = nullptr;
-      a.flops += 2.0 * a.B * a.Hout * a.Wout * 192.0 * 192.0;
+      a.flops += 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cout;
     }
   }
   // bf16x3 where it is faster: the IGDN-backward prologue (3 prefetched operands) and the 2-wave

@@ -45,7 +45,9 @@ def _pair(C, B, H, W):
 SHAPES = [(64, 2, 64, 64), (64, 1, 50, 70), (128, 1, 37, 41), (192, 2, 64, 48), (192, 1, 256, 256),
           (256, 1, 96, 80), (192, 3, 128, 192), (256, 1, 200, 264),
           # >= 1024 tiles in gs2.fwd: the IGDN runs as the post-phase of the convolution launch (conv_mfma.hip POST)
-          (192, 2, 512, 512), (192, 2, 520, 504)]
+          (192, 2, 512, 512), (192, 2, 520, 504),
+          # the same at cfg 4's width (README.md:58-60): 256 x 256 tile, the post-phase in four 64-row parts
+          (256, 1, 520, 504), (256, 2, 512, 512)]
 
 
 @pytest.mark.parametrize("C,B,H,W", SHAPES)
