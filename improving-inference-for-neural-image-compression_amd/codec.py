@@ -143,6 +143,13 @@ class SGACodec:
         arr = (C.c_int32 * max(len(ids), 1))(*ids)
         self._chk(self.lib.sga_set_image_ids(self.handle, arr, len(ids)), "sga_set_image_ids")
 
+    def set_image_seeds(self, seeds=None):
+        """Per-image noise keys for a launch that pools images of several reference batches (None: every image uses
+        the `seed` of the run): seeds[b] = the seed of the b-th image's reference batch."""
+        seeds = [] if seeds is None else [int(s) & 0xFFFFFFFFFFFFFFFF for s in seeds]
+        arr = (C.c_uint64 * max(len(seeds), 1))(*seeds)
+        self._chk(self.lib.sga_set_image_seeds(self.handle, arr, len(seeds)), "sga_set_image_seeds")
+
     # ---- the session interactions ------------------------------------------------------------
     def encode(self, x):
         x = self._t(x)

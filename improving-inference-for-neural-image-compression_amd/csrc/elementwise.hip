@@ -52,7 +52,7 @@ __device__ __forceinline__ float sgnf(float t) { return (t > 0.f) - (t < 0.f); }
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void sample_one(float x, int64_t idx, const float* __restrict__ u, float T, int it,
                                            unsigned k0, unsigned k1, int stream_id, int mode,
-                                           const int* __restrict__ img_ids, int64_t per_img,
+                                           const int4* __restrict__ img_ids, int64_t per_img,
                                            float& vt_out, float& dvt_out) {
   float u0, u1;
   if (u) {
@@ -62,10 +62,14 @@ __device__ __forceinline__ void sample_one(float x, int64_t idx, const float* __
     uint32_t r[4];
     // counter = element index within the REFERENCE batch: image img_ids[b] of it (sga_set_image_ids),
     // so a shard draws the noise its images would have drawn in the un-sharded batch
+    // img_ids[b] = {position in the reference batch, that batch's seed (lo, hi), seed valid}: images pooled from several
+    // reference batches into one launch each keep the key of their own batch (sga_set_image_seeds)
     int64_t ctr = idx;
     if (img_ids) {
       const int64_t b = idx / per_img;
-      ctr = (int64_t)img_ids[b] * per_img + (idx - b * per_img);
+      const int4 ik = img_ids[b];
+      ctr = (int64_t)ik.x * per_img + (idx - b * per_img);
+      if (ik.w) { k0 = (unsigned)ik.y; k1 = (unsigned)ik.z; }
     }
     philox4x32_10((uint32_t)ctr, (uint32_t)((uint64_t)ctr >> 32), (uint32_t)it,
                   (uint32_t)stream_id, k0, k1, r);
@@ -103,7 +107,7 @@ __device__ __forceinline__ void sample_one(float x, int64_t idx, const float* __
 __device__ __forceinline__ void sample_range(const float* __restrict__ v, const float* __restrict__ u,
                          const StepCtx* __restrict__ ctx, int stream_id, float* __restrict__ vt,
                          float* __restrict__ dvt, int64_t n, int mode,
-                         const int* __restrict__ img_ids, int64_t per_img, int bid, int nblk) {
+                         const int4* __restrict__ img_ids, int64_t per_img, int bid, int nblk) {
   const float T = ctx->T;
   const int it = ctx->it;
   const unsigned k0 = ctx->seed_lo, k1 = ctx->seed_hi;
@@ -119,7 +123,7 @@ __device__ __forceinline__ void sample_range(const float* __restrict__ v, const 
 __global__ void k_sample(const float* __restrict__ v, const float* __restrict__ u,
                          const StepCtx* __restrict__ ctx, int stream_id, float* __restrict__ vt,
                          float* __restrict__ dvt, int64_t n, int mode,
-                         const int* __restrict__ img_ids, int64_t per_img) {
+                         const int4* __restrict__ img_ids, int64_t per_img) {
   sample_range(v, u, ctx, stream_id, vt, dvt, n, mode, img_ids, per_img, blockIdx.x, gridDim.x);
 }
 
@@ -127,7 +131,7 @@ __global__ void k_sample(const float* __restrict__ v, const float* __restrict__ 
 __global__ void k_sample_yz(const float* __restrict__ y, float* __restrict__ yt, float* __restrict__ dyt,
                             int64_t ny, const float* __restrict__ z, float* __restrict__ zt,
                             float* __restrict__ dzt, int64_t nz, const StepCtx* __restrict__ ctx, int mode,
-                            const int* __restrict__ img_ids, int B, int gy) {
+                            const int4* __restrict__ img_ids, int B, int gy) {
   if ((int)blockIdx.x < gy)
     sample_range(y, nullptr, ctx, 0, yt, dyt, ny, mode, img_ids, ny / B, blockIdx.x, gy);
   else
@@ -317,12 +321,13 @@ __global__ void k_factorized_pdf(const float* __restrict__ zt, const float* __re
 __global__ void k_bb_sample_z(const float* __restrict__ zml, const float* __restrict__ eps_in,
                               const StepCtx* __restrict__ ctx, int stream_id, int n_per_img, int C,
                               float* __restrict__ zt, float* __restrict__ jac_lv,
-                              ImgSums* __restrict__ sums, const int* __restrict__ img_ids) {
+                              ImgSums* __restrict__ sums, const int4* __restrict__ img_ids) {
   __shared__ double sh[16];
   const int b = blockIdx.y;
-  const size_t ctr_base = (size_t)(img_ids ? img_ids[b] : b) * n_per_img;
+  const int4 ik = img_ids ? img_ids[b] : int4{b, 0, 0, 0};
+  const size_t ctr_base = (size_t)ik.x * n_per_img;
   const int it = ctx->it;
-  const unsigned k0 = ctx->seed_lo, k1 = ctx->seed_hi;
+  const unsigned k0 = ik.w ? (unsigned)ik.y : ctx->seed_lo, k1 = ik.w ? (unsigned)ik.z : ctx->seed_hi;
   double acc[1] = {0.0};
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_per_img; e += gridDim.x * blockDim.x) {
     const size_t idx = (size_t)b * n_per_img + e;
@@ -654,7 +659,7 @@ __global__ void k_step_boundary(float* __restrict__ py, const float* __restrict_
                                 const float* __restrict__ gaz, const float* __restrict__ gbz,
                                 float* __restrict__ jz, float* __restrict__ mz, float* __restrict__ vz,
                                 float* __restrict__ zt, int64_t nz, StepCtx* __restrict__ ctx, int gy, int mode,
-                                const int* __restrict__ img_ids, int B, int H, int W, ImgSums* sums,
+                                const int4* __restrict__ img_ids, int B, int H, int W, ImgSums* sums,
                                 float* trace, const float* __restrict__ Ttab, const float* __restrict__ lrtab,
                                 unsigned* __restrict__ ticket) {
   __shared__ int last;
@@ -832,7 +837,7 @@ inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
 #define LAUNCH_RET() return (int)hipGetLastError()
 
 int launch_sample(const float* v, const float* u, const StepCtx* ctx, int stream_id, float* vt,
-                  float* dvt, int64_t n, hipStream_t s, int mode, const int* img_ids, int64_t per_img) {
+                  float* dvt, int64_t n, hipStream_t s, int mode, const int4* img_ids, int64_t per_img) {
   hipLaunchKernelGGL(k_sample, dim3(grid_for(n)), dim3(256), 0, s, v, u, ctx, stream_id, vt, dvt, n,
                      mode, img_ids, per_img > 0 ? per_img : n);
   LAUNCH_RET();
@@ -946,7 +951,7 @@ int launch_finalize_step(ImgSums* sums, StepCtx* ctx, int B, int H, int W, float
 
 int launch_step_boundary(float* py, const float* gay, const float* gby, float* jy, float* my, float* vy, float* yt,
                          int64_t ny, float* pz, const float* gaz, const float* gbz, float* jz, float* mz, float* vz,
-                         float* zt, int64_t nz, StepCtx* ctx, int mode, const int* img_ids, int B, int H, int W,
+                         float* zt, int64_t nz, StepCtx* ctx, int mode, const int4* img_ids, int B, int H, int W,
                          ImgSums* sums, float* trace, const float* Ttab, const float* lrtab, unsigned* ticket,
                          hipStream_t s) {
   // at most 512 workgroups: each ends with an atomic on ONE address (1632 of them serialise to 25 us), while
@@ -963,7 +968,7 @@ int launch_step_boundary(float* py, const float* gay, const float* gby, float* j
 }
 
 int launch_sample_yz(const float* y, float* yt, float* dyt, int64_t ny, const float* z, float* zt, float* dzt,
-                     int64_t nz, const StepCtx* ctx, int mode, const int* img_ids, int B, hipStream_t s) {
+                     int64_t nz, const StepCtx* ctx, int mode, const int4* img_ids, int B, hipStream_t s) {
   const int gy = grid_for(ny), gz = grid_for(nz);
   hipLaunchKernelGGL(k_sample_yz, dim3(gy + gz), dim3(256), 0, s, y, yt, dyt, ny, z, zt, dzt, nz, ctx, mode,
                      img_ids, B, gy);
@@ -1022,7 +1027,7 @@ int launch_relu_mask(const float* g, const float* act, float* out, int64_t n, hi
 
 int launch_bb_sample_z(const float* zml, const float* eps_in, const StepCtx* ctx, int stream_id,
                        int B, int npix, int C, float* zt, float* jac_lv, ImgSums* sums,
-                       hipStream_t s, const int* img_ids) {
+                       hipStream_t s, const int4* img_ids) {
   const int n_per_img = npix * C;
   hipLaunchKernelGGL(k_bb_sample_z, dim3(grid_for(n_per_img, 256, 256), B), dim3(256), 0, s, zml,
                      eps_in, ctx, stream_id, n_per_img, C, zt, jac_lv, sums, img_ids);

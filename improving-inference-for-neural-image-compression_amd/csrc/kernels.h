@@ -17,11 +17,12 @@ struct ImgSums {
 // SGA relaxation sga.py:86-98 / :111-121 (+ tfp RelaxedOneHotCategorical.sample).
 // u != null: injected uniforms [n][2]; else Philox keyed by ctx (stream_id 0 = y, 1 = z).
 // mode: sga_relaxation (0 SGA, 1 deterministic annealing, 2 uniform noise, 3 STE, 4 none)
-// img_ids (device, [n / per_img] ints) or null: position of each image in its reference batch; the
-// Philox counter of element e of image b is img_ids[b] * per_img + e (sga_set_image_ids)
+// img_ids (device, [n / per_img] int4) or null: {position of the image in its reference batch, seed lo, seed hi, seed valid};
+// the Philox counter of element e of image b is img_ids[b].x * per_img + e (sga_set_image_ids), its key the image's own
+// seed when valid (sga_set_image_seeds), else the run's
 int launch_sample(const float* v, const float* u, const StepCtx* ctx, int stream_id,
                   float* vt, float* dvt, int64_t n, hipStream_t s, int mode = 0,
-                  const int* img_ids = nullptr, int64_t per_img = 0);
+                  const int4* img_ids = nullptr, int64_t per_img = 0);
 
 // Factorized prior on z_tilde [B, npix, C]: accumulates -ln p into sums[b].z_nats and writes
 // d rd_loss / d z_tilde (rate term) to g_zt.  p_out / dp_out (optional): raw mass and dp/dv.
@@ -76,12 +77,12 @@ int launch_finalize_step(ImgSums* sums, StepCtx* ctx, int B, int H, int W, float
 // (k_step_boundary); `ticket`: a zero-initialised device counter owned by the handle
 int launch_step_boundary(float* py, const float* gay, const float* gby, float* jy, float* my, float* vy, float* yt,
                          int64_t ny, float* pz, const float* gaz, const float* gbz, float* jz, float* mz, float* vz,
-                         float* zt, int64_t nz, StepCtx* ctx, int mode, const int* img_ids, int B, int H, int W,
+                         float* zt, int64_t nz, StepCtx* ctx, int mode, const int4* img_ids, int B, int H, int W,
                          ImgSums* sums, float* trace, const float* Ttab, const float* lrtab, unsigned* ticket,
                          hipStream_t s);
 // the y and z relaxations / Adam updates of one SGA iteration in one launch each (Philox noise only)
 int launch_sample_yz(const float* y, float* yt, float* dyt, int64_t ny, const float* z, float* zt, float* dzt,
-                     int64_t nz, const StepCtx* ctx, int mode, const int* img_ids, int B, hipStream_t s);
+                     int64_t nz, const StepCtx* ctx, int mode, const int4* img_ids, int B, hipStream_t s);
 int launch_adam_latent_yz(float* py, const float* gay, const float* gby, const float* jy, float* my, float* vy,
                           int64_t ny, float* pz, const float* gaz, const float* gbz, const float* jz,
                           float* mz, float* vz, int64_t nz, const StepCtx* ctx, hipStream_t s);
@@ -110,7 +111,7 @@ int launch_copy(float* dst, const float* src, int64_t n, hipStream_t s);
 // jac_lv = d z_tilde / d logvar and accumulates sum ln q(z_tilde) (utils.py:72-77).
 int launch_bb_sample_z(const float* zml, const float* eps_in, const StepCtx* ctx, int stream_id,
                        int B, int npix, int C, float* zt, float* jac_lv, ImgSums* sums,
-                       hipStream_t s, const int* img_ids = nullptr);
+                       hipStream_t s, const int4* img_ids = nullptr);
 // prior DENSITY p(z_tilde) = dCDF/dz (learned_prior.py:164-185) with lower bound, rate gradient
 // (needs the second derivative of the CDF network)
 int launch_factorized_pdf(const float* zt, const float* eb_packed, const StepCtx* ctx, int B,

@@ -129,7 +129,9 @@ struct sga_handle {
   int gmain_B = 0, gmain_H = 0, gmain_W = 0;
   ImgSums* sums = nullptr;
   StepCtx* ctx = nullptr;
-  int* img_ids = nullptr;        // [max_batch] position of each image in its reference batch (sga_set_image_ids)
+  int4* img_ids = nullptr;       // [max_batch] {position of the image in its reference batch (sga_set_image_ids), its batch's seed
+                                 //   lo / hi, seed valid (sga_set_image_seeds)}
+  std::vector<int4> img_keys;    // host copy
   std::vector<float> hT, hLr;    // host tables (kept alive across the async upload)
 
   Geom geom_zeroed;              // geometry for which xpad/gpad borders are known zero
@@ -1351,11 +1353,11 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     TRY(dev_alloc(h, &p, sizeof(StepCtx)));
     h->ctx = (StepCtx*)p;
     if (hipMemset(p, 0, sizeof(StepCtx)) != hipSuccess) return fail(SGA_ERR_HIP);
-    TRY(dev_alloc(h, &p, sizeof(int) * B));
-    h->img_ids = (int*)p;
-    std::vector<int> ident(B);
-    for (size_t i = 0; i < B; ++i) ident[i] = (int)i;
-    if (hipMemcpy(p, ident.data(), sizeof(int) * B, hipMemcpyHostToDevice) != hipSuccess) return fail(SGA_ERR_HIP);
+    TRY(dev_alloc(h, &p, sizeof(int4) * B));
+    h->img_ids = (int4*)p;
+    h->img_keys.resize(B);
+    for (size_t i = 0; i < B; ++i) h->img_keys[i] = int4{(int)i, 0, 0, 0};
+    if (hipMemcpy(p, h->img_keys.data(), sizeof(int4) * B, hipMemcpyHostToDevice) != hipSuccess) return fail(SGA_ERR_HIP);
   }
   if (hipDeviceSynchronize() != hipSuccess) return fail(SGA_ERR_HIP);
   const char* env = getenv("SGA_NO_GRAPH");
@@ -1498,15 +1500,25 @@ int sga_latent_shape(const sga_handle* h, int H, int W, int* yh, int* yw, int* z
 
 int sga_set_image_ids(sga_handle* h, const int32_t* ids, int n) {
   if (!h || n < 0 || n > h->cfg.max_batch || (n > 0 && !ids)) return SGA_ERR_BAD_ARG;
-  std::vector<int> v(h->cfg.max_batch);
-  for (int i = 0; i < h->cfg.max_batch; ++i) {
-    v[i] = i < n ? ids[i] : i;
-    if (v[i] < 0) return SGA_ERR_BAD_ARG;
-  }
+  for (int i = 0; i < n; ++i)
+    if (ids[i] < 0) return SGA_ERR_BAD_ARG;
+  for (int i = 0; i < h->cfg.max_batch; ++i) h->img_keys[i].x = i < n ? ids[i] : i;
   // the captured step graph reads this array through a fixed device pointer: wait for work in
   // flight, then overwrite the contents (no re-capture needed)
   HIPCHK(h, hipDeviceSynchronize());
-  HIPCHK(h, hipMemcpy(h->img_ids, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->img_ids, h->img_keys.data(), sizeof(int4) * h->img_keys.size(), hipMemcpyHostToDevice));
+  return SGA_OK;
+}
+
+int sga_set_image_seeds(sga_handle* h, const uint64_t* seeds, int n) {
+  if (!h || n < 0 || n > h->cfg.max_batch || (n > 0 && !seeds)) return SGA_ERR_BAD_ARG;
+  for (int i = 0; i < h->cfg.max_batch; ++i) {
+    int4& k = h->img_keys[i];
+    if (i < n) { k.y = (int)(unsigned)(seeds[i] & 0xffffffffu); k.z = (int)(unsigned)(seeds[i] >> 32); k.w = 1; }
+    else { k.y = 0; k.z = 0; k.w = 0; }
+  }
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(h->img_ids, h->img_keys.data(), sizeof(int4) * h->img_keys.size(), hipMemcpyHostToDevice));
   return SGA_OK;
 }
 

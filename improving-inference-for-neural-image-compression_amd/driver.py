@@ -82,6 +82,28 @@ def shard_batch(indices, rank: int, world: int, batch_no: int = 0):
     return indices[(rank - batch_no) % world::world]
 
 
+def plan_launches(num_images, batch_size, rank, world, seed, max_batch, pool=True):
+    """The launches of one rank: lists of (image, position in its reference batch, batch seed, loss_scale, batch number).
+    One noise stream per reference batch (seed + 1000003 * batch number); an image's noise is keyed on its position in
+    that batch (sga_set_image_ids) and on that batch's seed (sga_set_image_seeds), so results do not depend on world
+    size, chunking or pooling.  A launch holds consecutive work items with the same loss_scale = 1 / len(reference
+    batch) (the batch means of sga.py:147,150), up to the workspace size; items of DIFFERENT reference batches pool
+    into one launch (a rank that holds one Tecnick image of each 7-image batch then runs B > 1 per launch) unless
+    pool=False: the early-stopping scripts decide on their batch objective (map.py:188, ste.py:189)."""
+    work = []
+    for b_i, batch in enumerate(reference_batches(num_images, batch_size)):
+        for i in shard_batch(batch, rank, world, b_i):
+            work.append((i, i - batch[0], seed + 1000003 * b_i, 1.0 / len(batch), b_i))
+    launches = []
+    for item in work:
+        cur = launches[-1] if launches else None
+        if cur and len(cur) < max_batch and cur[-1][3] == item[3] and (pool or cur[-1][4] == item[4]):
+            cur.append(item)
+        else:
+            launches.append([item])
+    return launches
+
+
 def gather_metrics(local_idx, local_met, num_images, dist=None, device=None, nfields=None):
     """All-gather [n_local, F] metrics + their image indices; returns [num_images, F] on every
     rank.  dist=None: single process."""
@@ -207,60 +229,58 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
     if method in ("mbt2018", "map") and medians is None:
         medians = getattr(codec, "medians", None)       # from the checkpoint's `quantiles`
     log_sched, log_rate, log_Tub, log_t0 = "exp0", annealing_rate, T_ub, t0
+    launches = plan_launches(N, bs, rank, world, seed, codec.max_batch, pool=method not in ("map", "ste"))
     try:
-        for b_i, batch in enumerate(reference_batches(N, bs)):
-            mine = shard_batch(batch, rank, world, b_i)
-            loss_scale = 1.0 / len(batch)                   # the batch means of sga.py:147,150
-            # one noise stream per reference batch; an image's noise is keyed on its position in that
-            # batch (sga_set_image_ids), so results do not depend on world size or chunking
-            sd = seed + 1000003 * b_i
-            for s in range(0, len(mine), codec.max_batch):  # workspace-sized chunks of the shard
-                idx = mine[s:s + codec.max_batch]
-                codec.set_image_ids([i - batch[0] for i in idx])
-                if method == "bb_sga":
-                    _, _, met, tr, _ = codec.bb_run(X[idx], lmbda, its=its, r_its=r_its, lr=lr, r_lr=r_lr,
-                                                    annealing_rate=annealing_rate, t0=t0, T_ub=T_ub,
-                                                    seed=sd, loss_scale=loss_scale, trace=verbose)
-                elif method == "mbt2018":
-                    kw = {} if base_scale_bound is None else dict(scale_bound=base_scale_bound)
-                    _, _, met = codec.base_compress(X[idx], medians=medians, **kw)      # default 0.11: mbt2018.py:80
-                    tr = None
-                elif method in SIBLINGS:
-                    relax, sched, s_lr, s_r, s_Tub, s_t0, early = SIBLINGS[method]
-                    log_sched, log_rate, log_Tub, log_t0 = sched, s_r, s_Tub, s_t0
-                    codec.set_relaxation(relax, sched)
-                    try:
-                        if early:
-                            _, _, met, _ = run_early_stop(codec, X[idx], lmbda, method=method, its=its, lr=s_lr,
-                                                          seed=sd, loss_scale=loss_scale, medians=medians,
-                                                          log=log if verbose else None)
-                            tr = None
-                        else:
-                            _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=s_lr, annealing_rate=s_r,
-                                                      t0=s_t0, T_ub=s_Tub, seed=sd, loss_scale=loss_scale,
-                                                      trace=verbose)
-                    finally:
-                        codec.set_relaxation("sga", "exp0")
-                elif verbose:
-                    met = run_verbose(codec, X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate, t0=t0,
-                                      T_ub=T_ub, seed=sd, loss_scale=loss_scale, log_itv=log_itv, log=log)
-                    tr = None
-                else:
-                    _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate,
-                                              t0=t0, T_ub=T_ub, seed=sd, loss_scale=loss_scale,
-                                              trace=verbose)
-                if verbose and tr is not None:
-                    tr = tr.cpu().numpy()
-                    for it in range(its):
-                        if it % log_itv == 0 or it + 1 == its:      # sga.py:216,232-233
-                            T = annealed_temperature(it, log_rate, log_Tub, scheme=log_sched, t0=log_t0)
-                            log("it=%d, T=%.3f rd_loss=%.4f mse=%.3f bpp=%.4f psnr=%.4f" %
-                                (it, T, tr[it, 0], tr[it, 1], tr[it, 2], tr[it, 3]))
-                local_idx += idx
-                local_met.append(met.cpu().numpy())
+        for chunk in launches:
+            idx = [c[0] for c in chunk]
+            loss_scale, sd = chunk[0][3], chunk[0][2]
+            codec.set_image_ids([c[1] for c in chunk])
+            codec.set_image_seeds([c[2] for c in chunk])
+            if method == "bb_sga":
+                _, _, met, tr, _ = codec.bb_run(X[idx], lmbda, its=its, r_its=r_its, lr=lr, r_lr=r_lr,
+                                                annealing_rate=annealing_rate, t0=t0, T_ub=T_ub,
+                                                seed=sd, loss_scale=loss_scale, trace=verbose)
+            elif method == "mbt2018":
+                kw = {} if base_scale_bound is None else dict(scale_bound=base_scale_bound)
+                _, _, met = codec.base_compress(X[idx], medians=medians, **kw)      # default 0.11: mbt2018.py:80
+                tr = None
+            elif method in SIBLINGS:
+                relax, sched, s_lr, s_r, s_Tub, s_t0, early = SIBLINGS[method]
+                log_sched, log_rate, log_Tub, log_t0 = sched, s_r, s_Tub, s_t0
+                codec.set_relaxation(relax, sched)
+                try:
+                    if early:
+                        _, _, met, _ = run_early_stop(codec, X[idx], lmbda, method=method, its=its, lr=s_lr,
+                                                      seed=sd, loss_scale=loss_scale, medians=medians,
+                                                      log=log if verbose else None)
+                        tr = None
+                    else:
+                        _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=s_lr, annealing_rate=s_r,
+                                                  t0=s_t0, T_ub=s_Tub, seed=sd, loss_scale=loss_scale,
+                                                  trace=verbose)
+                finally:
+                    codec.set_relaxation("sga", "exp0")
+            elif verbose:
+                met = run_verbose(codec, X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate, t0=t0,
+                                  T_ub=T_ub, seed=sd, loss_scale=loss_scale, log_itv=log_itv, log=log)
+                tr = None
+            else:
+                _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate,
+                                          t0=t0, T_ub=T_ub, seed=sd, loss_scale=loss_scale,
+                                          trace=verbose)
+            if verbose and tr is not None:
+                tr = tr.cpu().numpy()
+                for it in range(its):
+                    if it % log_itv == 0 or it + 1 == its:      # sga.py:216,232-233
+                        T = annealed_temperature(it, log_rate, log_Tub, scheme=log_sched, t0=log_t0)
+                        log("it=%d, T=%.3f rd_loss=%.4f mse=%.3f bpp=%.4f psnr=%.4f" %
+                            (it, T, tr[it, 0], tr[it, 1], tr[it, 2], tr[it, 3]))
+            local_idx += idx
+            local_met.append(met.cpu().numpy())
     finally:
         # an exception in a run must not leave the handle drawing noise for stale batch positions
         codec.set_image_ids(None)
+        codec.set_image_seeds(None)
     local_met = np.concatenate(local_met, 0) if local_met else np.zeros((0, len(fields)), np.float32)
     device = codec.device if (dist is not None and dist.is_initialized()
                               and dist.get_backend() == "nccl") else None
@@ -311,10 +331,14 @@ def compress(args, weights=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # one process per GPU, launched by torch.distributed.run (RANK / WORLD_SIZE / MASTER_* in the environment); at
+    # world size 1 the same path runs (RCCL group of one, device all_gather) when the launcher set the variables
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist
         if not dist.is_initialized():
-            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group(backend=os.environ.get("SGA_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank}")
+                                    if os.environ.get("SGA_DIST_BACKEND", "nccl") == "nccl" else None)
     X = load_images(args.input_file)
     N, H, W, _ = X.shape
     if args.lmbda < 0:
@@ -335,7 +359,10 @@ def compress(args, weights=None):
                                  "map.py:83) but the checkpoint has no entropy_bottleneck/quantiles")
     bs = get_eval_batch_size(H * W)
     per_rank = -(-min(bs, N) // world)
-    max_batch = args.max_batch or per_rank
+    # a rank's share of one reference batch can be a single large image (Tecnick: batches of 7 on 8 GPUs): let its
+    # launches pool images of consecutive batches up to ~6 Mpixel (4 Tecnick images: 0.78 instead of 0.73 of the roofline)
+    pool = min(-(-N // world), max(1, int(6e6 // (H * W))))
+    max_batch = args.max_batch or max(per_rank, pool)
     sb = getattr(args, "scale_bound", None)
     codec = SGACodec(weights, args.num_filters, max_batch, H, W, device=f"cuda:{local_rank}",
                      bits_back=bb, precision=getattr(args, "precision", "f32"),

@@ -118,6 +118,12 @@ int sga_set_scale_bound(sga_handle* h, float scale_bound);
  * to the same images' results in the un-sharded batch bit for bit, for any world size or chunking.
  * Synchronises the device. */
 int sga_set_image_ids(sga_handle* h, const int32_t* ids, int n);
+/* Pooling: a rank whose share of every reference batch is a single image (Tecnick: batches of 7 on 8 GPUs,
+ * configs.py:5-9) can run images of CONSECUTIVE reference batches in one launch when their loss_scale agree.  Each
+ * reference batch has its own noise op, i.e. its own seed: seeds[b] = the seed of the b-th image's batch (HOST pointer,
+ * n <= max_batch); the device RNG then keys image b on seeds[b] instead of the `seed` argument of the run.
+ * n = 0 restores "every image uses the run's seed".  Synchronises the device. */
+int sga_set_image_seeds(sga_handle* h, const uint64_t* seeds, int n);
 
 /* ---- sga.py:207  y_init, z_init = sess.run([y_init, z_init], {x}) ---------------------- */
 int sga_encode(sga_handle* h, const float* x, int B, int H, int W,

@@ -145,3 +145,55 @@ def test_bench_launch_line_at_world_size_8(tmp_path):
     assert plain["n_gpus"] == 1
     assert np.array_equal(m8[:2], np.load(tmp_path / "m1.npy"), equal_nan=True)
     assert not np.array_equal(m8[2:4], m8[:2])          # other ranks work on other images
+
+
+def test_pooled_launch_keeps_each_images_own_batch_noise():
+    """sga_set_image_seeds: one launch holding images of two DIFFERENT reference batches (Tecnick on 8 GPUs: a rank has
+    one image of each 7-image batch) gives each image the noise of its own batch -- image A (batch 0, position 2,
+    seed s0) pooled with image B (batch 1, position 0, seed s1) ends exactly where it ends when it shares the launch
+    with another image of batch 0 under the plain run seed s0, and likewise for B."""
+    from sga_amd.codec import SGACodec
+    codec = SGACodec(sga_amd.make_synthetic_weights(C, seed=0), C, 2, H, W)
+    x = np.random.RandomState(21).rand(4, H, W, 3).astype(np.float32)       # A, A2 (batch 0), B2, B (batch 1)
+    s0, s1 = 3, 3 + 1000003
+    kw = dict(its=ITS, loss_scale=1.0 / 7)
+    codec.set_image_ids([2, 5]); codec.set_image_seeds(None)
+    ref_a = codec.run(x[[0, 1]], 0.01, seed=s0, **kw)                      # A in slot 0, its batch-mate beside it
+    codec.set_image_ids([4, 0])
+    ref_b = codec.run(x[[2, 3]], 0.01, seed=s1, **kw)                      # B in slot 1
+    codec.set_image_ids([2, 0]); codec.set_image_seeds([s0, s1])
+    pooled = codec.run(x[[0, 3]], 0.01, seed=12345, **kw)                  # the run seed is not used for keyed images
+    assert torch.equal(pooled[0][0], ref_a[0][0]) and torch.equal(pooled[1][0], ref_a[1][0])
+    assert torch.equal(pooled[0][1], ref_b[0][1]) and torch.equal(pooled[1][1], ref_b[1][1])
+    assert torch.equal(pooled[2][:, [0, 1, 4, 5, 6]], torch.stack([ref_a[2][0], ref_b[2][1]])[:, [0, 1, 4, 5, 6]])
+    codec.set_image_seeds([s0, s0])                                        # B under the wrong batch's seed: other noise
+    wrong = codec.run(x[[0, 3]], 0.01, seed=12345, **kw)
+    assert torch.equal(wrong[0][0], ref_a[0][0]) and not torch.equal(wrong[0][1], ref_b[0][1])
+    codec.set_image_ids(None); codec.set_image_seeds(None)
+    codec.close()
+
+
+def test_driver_compress_under_rccl_at_world_size_1(tmp_path):
+    """`python -m sga_amd.driver ... compress` (not only bench.py) as torch.distributed.run starts it: the launcher's
+    RANK / WORLD_SIZE / MASTER_* make `compress` call init_process_group("nccl") and gather the metrics with a device
+    all_gather (RCCL) -- at world size 1, the only size a 1-GPU box can run; results equal the plain command's."""
+    X = (np.random.RandomState(9).rand(5, 48, 64, 3) * 255).astype(np.uint8)
+    np.save(tmp_path / "x.npy", X)
+    runname = "mbt2018-num_filters=64-lmbda=0.02"
+    base = [sys.executable, "-m", "sga_amd.driver", "--num_filters", "64", "compress", "--sga_its", "15", "--t0", "4",
+            "--synthetic_weights", "--max_batch", "2", runname, str(tmp_path / "x.npy")]
+    outs = {}
+    for tag, env in (("plain", {}), ("rccl", dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                                                  MASTER_PORT=str(29600 + os.getpid() % 90)))):
+        out = tmp_path / tag
+        cmd = base[:6] + ["--results_dir", str(out)] + base[6:]
+        p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, GPU_MAX_HW_QUEUES="2", **env), capture_output=True,
+                           text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        files = os.listdir(out)
+        assert len(files) == 1
+        outs[tag] = dict(np.load(out / files[0]))
+        assert "Avg est_bpp" in p.stdout
+    for k in outs["plain"]:
+        assert outs["plain"][k].shape == (5,)
+        assert np.array_equal(outs["plain"][k], outs["rccl"][k], equal_nan=True), k

@@ -173,15 +173,22 @@ class _FakeCodec:
         self.max_batch = max_batch
         self.device = torch.device("cpu")
         self.ids = None
+        self.seeds = None
+        self.launch_sizes = []
 
     def set_image_ids(self, ids=None):
         self.ids = None if ids is None else [int(i) for i in ids]
+
+    def set_image_seeds(self, seeds=None):
+        self.seeds = None if seeds is None else [int(i) for i in seeds]
 
     def run(self, x, lmbda, its=2000, loss_scale=None, trace=False, seed=0, **kw):
         x = torch.as_tensor(x)
         ids = torch.tensor(self.ids if self.ids is not None else list(range(len(x))), dtype=torch.float32)
         assert len(ids) == len(x)
-        base = x.mean((1, 2, 3)) + loss_scale + 1e-3 * ids + 1e-5 * float(seed % 97)
+        self.launch_sizes.append(len(x))
+        sd = torch.tensor([float(s % 97) for s in (self.seeds if self.seeds else [seed] * len(x))])
+        base = x.mean((1, 2, 3)) + loss_scale + 1e-3 * ids + 1e-5 * sd
         m = torch.stack([base * (k + 1) for k in range(7)], dim=1)
         return None, None, m.float(), None
 
@@ -227,6 +234,35 @@ def test_sharded_run_and_gather_gloo_world2(tmp_path, monkeypatch, N, bs):
         got = np.load(tmp_path / f"r{r}.npz")
         for k in driver.EVAL_FIELDS:
             assert np.allclose(got[k], single[k], atol=1e-6), (r, k)
+
+
+def test_launches_pool_images_of_consecutive_reference_batches():
+    """Tecnick's pattern: 100 images in reference batches of 7 (configs.py:5-9) on 8 ranks -- every rank
+    holds ONE image of most batches.  Its launches pool images of consecutive batches (same loss_scale = 1/7; the
+    last batch of 2 has 1/2 and stays apart), each image keeping the position and the seed of its own batch, so
+    per-image results equal the un-pooled run; the early-stopping methods never pool across batches."""
+    N, bs, world = 100, 7, 8
+    X = np.random.RandomState(1).rand(N, 8, 8, 3).astype(np.float32)
+    old = driver.eval_batch_num_pixels
+    driver.eval_batch_num_pixels = bs * PIX
+    try:
+        want = driver.run_dataset(_FakeCodec(7), X, 0.01, its=3, seed=5)                 # single process, batch by batch
+        for rank in (0, 3, 7):
+            one, four = _FakeCodec(1), _FakeCodec(4)
+            a = driver.run_dataset(one, X, 0.01, its=3, seed=5, rank=rank, world=world)
+            b = driver.run_dataset(four, X, 0.01, its=3, seed=5, rank=rank, world=world)
+            mine = ~np.isnan(a["mse"])
+            assert 12 <= mine.sum() <= 13 and np.array_equal(mine, ~np.isnan(b["mse"]))
+            for k in driver.EVAL_FIELDS:
+                assert np.allclose(a[k][mine], want[k][mine], atol=1e-6) and np.allclose(b[k][mine], want[k][mine], atol=1e-6)
+            assert set(one.launch_sizes) == {1} and max(four.launch_sizes) == 4 and len(four.launch_sizes) <= 5
+            plan = driver.plan_launches(N, bs, rank, world, 5, 4, pool=False)               # map.py / ste.py
+            assert all(len({c[4] for c in launch}) == 1 for launch in plan)
+            plan = driver.plan_launches(N, bs, rank, world, 5, 4)
+            assert any(len({c[4] for c in launch}) > 1 for launch in plan)
+            assert all(len({c[3] for c in launch}) == 1 for launch in plan)                 # one loss_scale per launch
+    finally:
+        driver.eval_batch_num_pixels = old
 
 
 def test_shard_counts_balanced_and_gather_sized_from_them():
