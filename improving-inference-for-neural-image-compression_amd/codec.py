@@ -389,20 +389,115 @@ class SGACodec:
             self._ec_dev = device_tables
         return self._ec
 
-    def compress_latents(self, x_shape, y_hat, z_hat, device_tables=True) -> bytes:
+    # ---- the coder itself on the device (csrc/rans.hip) ---------------------------------------------------------
+    def _ec_tables(self, coder):
+        """The coder's CDF tables, lengths, offsets and the scale table as device tensors (cached per coder)."""
+        if getattr(self, "_ec_dev_tabs", None) is None or self._ec_dev_tabs[0] is not coder:
+            dev = self.device
+            self._ec_dev_tabs = (coder,
+                                 torch.as_tensor(coder.cdf.astype(np.int64), device=dev).to(torch.int32).contiguous(),
+                                 torch.as_tensor(coder.lens, device=dev).contiguous(),
+                                 torch.as_tensor(coder.offs, device=dev).contiguous(),
+                                 torch.as_tensor(coder.scale_table, dtype=torch.float64, device=dev).contiguous())
+        return self._ec_dev_tabs[1:]
+
+    def _ec_encode_device(self, coder, sym, tab):
+        """sym / tab (int32 device tensors) -> one blocked rANS stream (bytes), encoded by one lane per block."""
+        from . import entropy_coding as ec
+        cdf, lens, offs, _ = self._ec_tables(coder)
+        n = sym.numel()
+        nb = -(-n // ec.BLOCK)
+        cap = 16 + 8 * ec.BLOCK
+        slots = torch.empty(nb * cap, dtype=torch.uint8, device=self.device)
+        bb = torch.empty(nb, dtype=torch.int32, device=self.device)
+        s = self._enter()
+        _lib.check(self.lib, None, self.lib.sga_ec_encode(_ptr(sym), _ptr(tab), n, ec.BLOCK, _ptr(cdf), _ptr(lens),
+                                                          _ptr(offs), coder.stride, _ptr(slots), cap, _ptr(bb), s),
+                   "sga_ec_encode")
+        self._exit()
+        bbh = bb.cpu().numpy().astype(np.uint32)
+        if (bbh == 0).any():
+            raise RuntimeError("sga_ec_encode: output slot overflow")
+        off = np.concatenate([[0], np.cumsum(bbh[:-1], dtype=np.uint64)]).astype(np.uint64)
+        out = torch.empty(int(bbh.sum()), dtype=torch.uint8, device=self.device)
+        offd = torch.as_tensor(off.astype(np.int64), device=self.device)
+        s = self._enter()
+        _lib.check(self.lib, None, self.lib.sga_ec_compact(_ptr(slots), cap, _ptr(bb), _ptr(offd), nb, _ptr(out), s),
+                   "sga_ec_compact")
+        self._exit()
+        return ec.frame_blocks(bbh, out.cpu().numpy().tobytes())
+
+    def _ec_decode_device(self, coder, data: bytes, tab):
+        from . import entropy_coding as ec
+        cdf, lens, offs, _ = self._ec_tables(coder)
+        bbh, block, payload = ec.unframe_blocks(data)
+        n = tab.numel()
+        if bbh.size != -(-n // block):
+            raise ValueError("rans_decode: corrupt stream (block count)")
+        buf = torch.as_tensor(np.frombuffer(payload, np.uint8).copy() if payload else np.zeros(1, np.uint8), device=self.device)
+        off = torch.as_tensor(np.concatenate([[0], np.cumsum(bbh[:-1], dtype=np.int64)]).astype(np.int64), device=self.device)
+        bb = torch.as_tensor(bbh.astype(np.int64), device=self.device).to(torch.int32)
+        sym = torch.empty(n, dtype=torch.int32, device=self.device)
+        bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        s = self._enter()
+        _lib.check(self.lib, None, self.lib.sga_ec_decode(_ptr(buf), _ptr(off), _ptr(bb), int(bbh.size), _ptr(tab), n, block,
+                                                          _ptr(cdf), _ptr(lens), _ptr(offs), coder.stride, _ptr(sym),
+                                                          _ptr(bad), s), "sga_ec_decode")
+        self._exit()
+        if int(bad.item()):
+            raise ValueError("rans_decode: corrupt stream")
+        return sym
+
+    def _ec_symbols_device(self, coder, y_hat, mu, sigma, z_hat):
+        """(sym, tab[, r0]) of y (y_hat may be None: decoder) and of z (z_hat may be None) on the device."""
+        from . import entropy_coding as ec
+        _, _, _, scales = self._ec_tables(coder)
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=self.device)
+        bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        out = {}
+        s = self._enter()
+        if mu is not None:
+            n = mu.numel()
+            out["y_sym"], out["y_tab"], out["r0"] = (i32(n) if y_hat is not None else None), i32(n), i32(n)
+            _lib.check(self.lib, None,
+                       self.lib.sga_ec_y_symbols(_ptr(y_hat), _ptr(mu), _ptr(sigma), n, _ptr(scales), ec.SCALES_LEVELS,
+                                                 ec.MEAN_BINS, coder.y_tab0, _ptr(out["y_sym"]), _ptr(out["y_tab"]),
+                                                 _ptr(out["r0"]), _ptr(bad), s), "sga_ec_y_symbols")
+        self._exit()
+        out["bad"] = bad
+        return out
+
+    def compress_latents(self, x_shape, y_hat, z_hat, device_tables=True, on_device=True) -> bytes:
         """Entropy-code (y_hat, z_hat) of a batch into one byte string (cf. tfc.PackedTensors).  The stream records
         how its tables were built and their CRC32; device_tables=False gives the float64 host tables, which do
-        not depend on the GPU's math library (the interchange mode)."""
+        not depend on the GPU's math library (the interchange mode).  on_device: (mu, sigma) -> table indices -> rANS
+        bytes by the HIP kernels of csrc/rans.hip (one lane per 1024-symbol block); False: the same bytes from the host
+        coder (csrc_cpu/rans.c)."""
         from . import entropy_coding as ec
         coder = self._entropy_coder(device_tables=device_tables)
         y_hat, z_hat = self._t(y_hat), self._t(z_hat)
         mu, sigma = self.hyper_synthesis(z_hat, y_hat.shape[1], y_hat.shape[2])
+        if on_device:
+            ys = self._ec_symbols_device(coder, y_hat, mu, sigma, None)
+            nz = z_hat.numel()
+            z_sym = torch.empty(nz, dtype=torch.int32, device=self.device)
+            z_tab = torch.empty(nz, dtype=torch.int32, device=self.device)
+            s = self._enter()
+            _lib.check(self.lib, None, self.lib.sga_ec_z_symbols(_ptr(z_hat), nz, self.C, _ptr(z_sym), _ptr(z_tab),
+                                                                 _ptr(ys["bad"]), s), "sga_ec_z_symbols")
+            self._exit()
+            if int(ys["bad"].item()):
+                raise ValueError("y_hat / z_hat must hold integers; centred latents are not supported by this coder")
+            zb = self._ec_encode_device(coder, z_sym, z_tab)
+            yb = self._ec_encode_device(coder, ys["y_sym"], ys["y_tab"])
+            return ec.pack(tuple(x_shape), tuple(y_hat.shape), tuple(z_hat.shape), zb, yb, coder.table_mode,
+                           coder.table_crc())
         zb = coder.encode_z(z_hat.cpu().numpy())
         yb = coder.encode_y(y_hat.cpu().numpy(), mu.cpu().numpy(), sigma.cpu().numpy())
         return ec.pack(tuple(x_shape), tuple(y_hat.shape), tuple(z_hat.shape), zb, yb, coder.table_mode,
                        coder.table_crc())
 
-    def decompress_latents(self, blob: bytes):
+    def decompress_latents(self, blob: bytes, on_device=True):
         """-> (x_shape, y_hat, z_hat): z first, then (mu, sigma) = h_s(z_hat), then y."""
         from . import entropy_coding as ec
         x_shape, y_shape, z_shape, zb, yb, mode, crc = ec.unpack(blob, with_tables=True)
@@ -411,6 +506,18 @@ class SGACodec:
             raise ValueError("SGAC stream was coded with different CDF tables (mode %d, crc %08x; this decoder builds "
                              "%08x): other weights, or device-built tables from another GPU / ROCm build -- encode "
                              "with device_tables=False for streams that must travel" % (mode, crc, coder.table_crc()))
+        if on_device:
+            nz = int(np.prod(z_shape))
+            z_tab = torch.empty(nz, dtype=torch.int32, device=self.device)
+            s = self._enter()
+            _lib.check(self.lib, None, self.lib.sga_ec_z_symbols(None, nz, self.C, None, _ptr(z_tab), None, s),
+                       "sga_ec_z_symbols")
+            self._exit()
+            z_hat = self._ec_decode_device(coder, zb, z_tab).to(torch.float32).reshape(*z_shape)
+            mu, sigma = self.hyper_synthesis(z_hat, y_shape[1], y_shape[2])
+            ys = self._ec_symbols_device(coder, None, mu, sigma, None)
+            y_hat = (self._ec_decode_device(coder, yb, ys["y_tab"]) + ys["r0"]).to(torch.float32).reshape(*y_shape)
+            return x_shape, y_hat, z_hat
         z_hat = self._t(coder.decode_z(zb, z_shape))
         mu, sigma = self.hyper_synthesis(z_hat, y_shape[1], y_shape[2])
         y_hat = self._t(coder.decode_y(yb, mu.cpu().numpy(), sigma.cpu().numpy()))

@@ -85,3 +85,36 @@ int rans_decode(const uint8_t* in, size_t in_len, const int32_t* tab, size_t n, 
   }
   return 0;
 }
+
+/* ---- blocked streams ---------------------------------------------------------------------------
+ * A sequence of n symbols is cut into blocks of `block` symbols, each an independent rANS stream as above (own
+ * state, own flush).  Blocks are what the device coder (csrc/rans.hip: one lane per block) runs in parallel, and
+ * byte for byte what this function writes.  Output: the blocks' streams back to back in `out`; block_bytes[b] =
+ * length of block b.  Returns the total number of bytes, or 0 on overflow. */
+size_t rans_encode_blocked(const int32_t* sym, const int32_t* tab, size_t n, size_t block, const uint32_t* cdf,
+                           const int32_t* lens, const int32_t* offs, int stride, uint8_t* out, size_t cap,
+                           uint32_t* block_bytes, uint8_t* scratch, size_t scratch_cap) {
+  size_t total = 0, b = 0;
+  for (size_t s = 0; s < n; s += block, ++b) {
+    const size_t m = n - s < block ? n - s : block;
+    const size_t k = rans_encode(sym + s, tab + s, m, cdf, lens, offs, stride, scratch, scratch_cap);
+    if (k == 0 || total + k > cap) return 0;
+    memcpy(out + total, scratch + scratch_cap - k, k);
+    block_bytes[b] = (uint32_t)k;
+    total += k;
+  }
+  return total;
+}
+
+int rans_decode_blocked(const uint8_t* in, const uint32_t* block_bytes, size_t nblocks, const int32_t* tab, size_t n,
+                        size_t block, const uint32_t* cdf, const int32_t* lens, const int32_t* offs, int stride,
+                        int32_t* sym) {
+  size_t off = 0, b = 0;
+  for (size_t s = 0; s < n; s += block, ++b) {
+    if (b >= nblocks) return -1;
+    const size_t m = n - s < block ? n - s : block;
+    if (rans_decode(in + off, block_bytes[b], tab + s, m, cdf, lens, offs, stride, sym + s) != 0) return -1;
+    off += block_bytes[b];
+  }
+  return 0;
+}

@@ -35,6 +35,26 @@ TOTAL = 1 << PRECISION
 SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64          # sga.py:24-26
 MEAN_BINS = 8
 MAGIC = b"SGAC"
+BLOCK = 1024            # symbols per independent rANS stream (one device lane each; 8 bytes of overhead per block)
+
+
+def frame_blocks(block_bytes: np.ndarray, payload: bytes, block: int = BLOCK) -> bytes:
+    """One blocked stream: <u32 number of blocks> <u32 symbols per block> <u32 bytes of block b>* <the blocks' bytes>."""
+    bb = np.ascontiguousarray(block_bytes, dtype="<u4")
+    return struct.pack("<II", bb.size, block) + bb.tobytes() + payload
+
+
+def unframe_blocks(data: bytes):
+    if len(data) < 8:
+        raise ValueError("rans stream: truncated header")
+    nb, block = struct.unpack("<II", data[:8])
+    if nb > (len(data) - 8) // 4 or block <= 0:
+        raise ValueError("rans stream: corrupt header")
+    bb = np.frombuffer(data, "<u4", nb, 8).astype(np.uint32)
+    payload = data[8 + 4 * nb:]
+    if int(bb.sum()) != len(payload):
+        raise ValueError("rans stream: block lengths do not add up to the payload")
+    return bb, block, payload
 
 _lib = None
 
@@ -50,6 +70,12 @@ def _load():
         lib.rans_encode.argtypes = [i32p, i32p, C.c_size_t, u32p, i32p, i32p, C.c_int, u8p, C.c_size_t]
         lib.rans_decode.restype = C.c_int
         lib.rans_decode.argtypes = [u8p, C.c_size_t, i32p, C.c_size_t, u32p, i32p, i32p, C.c_int, i32p]
+        lib.rans_encode_blocked.restype = C.c_size_t
+        lib.rans_encode_blocked.argtypes = [i32p, i32p, C.c_size_t, C.c_size_t, u32p, i32p, i32p, C.c_int, u8p, C.c_size_t,
+                                            u32p, u8p, C.c_size_t]
+        lib.rans_decode_blocked.restype = C.c_int
+        lib.rans_decode_blocked.argtypes = [u8p, u32p, C.c_size_t, i32p, C.c_size_t, C.c_size_t, u32p, i32p, i32p, C.c_int,
+                                            i32p]
         _lib = lib
     return _lib
 
@@ -189,23 +215,29 @@ class EntropyCoder:
         lib = _load()
         sym = np.ascontiguousarray(sym.reshape(-1), np.int32)
         tab = np.ascontiguousarray(tab.reshape(-1), np.int32)
-        cap = 16 + 8 * sym.size
-        out = np.zeros(cap, np.uint8)
-        n = lib.rans_encode(_ptr(sym, C.c_int32), _ptr(tab, C.c_int32), sym.size, _ptr(self.cdf, C.c_uint32),
-                            _ptr(self.lens, C.c_int32), _ptr(self.offs, C.c_int32), self.stride,
-                            _ptr(out, C.c_uint8), cap)
+        nb = -(-sym.size // BLOCK)
+        cap = 16 * nb + 8 * sym.size
+        out, scratch = np.zeros(cap, np.uint8), np.zeros(16 + 8 * BLOCK, np.uint8)
+        bb = np.zeros(nb, np.uint32)
+        n = lib.rans_encode_blocked(_ptr(sym, C.c_int32), _ptr(tab, C.c_int32), sym.size, BLOCK,
+                                    _ptr(self.cdf, C.c_uint32), _ptr(self.lens, C.c_int32), _ptr(self.offs, C.c_int32),
+                                    self.stride, _ptr(out, C.c_uint8), cap, _ptr(bb, C.c_uint32),
+                                    _ptr(scratch, C.c_uint8), scratch.size)
         if n == 0:
             raise RuntimeError("rans_encode: output buffer overflow")
-        return out[cap - n:].tobytes()
+        return frame_blocks(bb, out[:n].tobytes())
 
     def _run_decode(self, data: bytes, tab):
         lib = _load()
         tab = np.ascontiguousarray(tab.reshape(-1), np.int32)
-        buf = np.frombuffer(data, np.uint8).copy()
+        bb, block, payload = unframe_blocks(data)
+        if bb.size != -(-tab.size // block):
+            raise ValueError("rans_decode: corrupt stream (block count)")
+        buf = np.frombuffer(payload, np.uint8).copy() if payload else np.zeros(1, np.uint8)
         sym = np.zeros(tab.size, np.int32)
-        rc = lib.rans_decode(_ptr(buf, C.c_uint8), buf.size, _ptr(tab, C.c_int32), tab.size,
-                             _ptr(self.cdf, C.c_uint32), _ptr(self.lens, C.c_int32),
-                             _ptr(self.offs, C.c_int32), self.stride, _ptr(sym, C.c_int32))
+        rc = lib.rans_decode_blocked(_ptr(buf, C.c_uint8), _ptr(bb, C.c_uint32), bb.size, _ptr(tab, C.c_int32), tab.size,
+                                     block, _ptr(self.cdf, C.c_uint32), _ptr(self.lens, C.c_int32),
+                                     _ptr(self.offs, C.c_int32), self.stride, _ptr(sym, C.c_int32))
         if rc != 0:
             raise ValueError("rans_decode: corrupt stream")
         return sym

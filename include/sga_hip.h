@@ -271,6 +271,33 @@ int sga_op_rate_terms(sga_handle* h, const float* y_tilde, const float* z_tilde,
                       int H, int W, float loss_scale, float* g_yt, float* g_ms, float* g_zt,
                       float* metrics, void* stream);
 
+/* ---- entropy coding of the quantised latents on the device --------------------------------------
+ * mbt2018.py:84-85,211-222 turns (y_hat, z_hat) into bytes with tfc's C++ range-coder ops.  Counterpart here: rANS
+ * (32-bit state, 16-bit probabilities, escape symbol) over BLOCKED streams -- the symbols are cut into blocks of
+ * `block`, each an independent stream, one lane per block -- byte for byte what the host coder
+ * (csrc_cpu/rans.c: rans_encode_blocked) writes for the same tables.  All pointers are DEVICE memory (cdf [ntables][stride]
+ * uint32 prefix sums with total 65536, lens / offs per table: entropy_coding.EntropyCoder builds them, from the
+ * device entropy-model kernels by default); no handle is involved.
+ *   sga_ec_y_symbols : sym = y_hat - rint(mu), tab = y_tab0 + level(sigma) * mean_bins + bin(mu - rint(mu)); r0 = rint(mu)
+ *                      (optional); y_hat = NULL: tab / r0 only (decoder).  bad (optional) counts non-integer y_hat.
+ *   sga_ec_z_symbols : sym = z_hat, tab = channel.
+ *   sga_ec_encode    : block b -> the END of slots[b * slot_cap .. (b + 1) * slot_cap), block_bytes[b] bytes (0: overflow;
+ *                      slot_cap = 16 + 8 * block always suffices).
+ *   sga_ec_compact   : slots -> out + block_off[b] (the caller's exclusive scan of block_bytes).
+ *   sga_ec_decode    : the inverse; bad counts corrupt blocks. */
+int sga_ec_y_symbols(const float* y_hat, const float* mu, const float* sigma, int64_t n, const double* scale_table,
+                     int levels, int mean_bins, int y_tab0, int32_t* sym, int32_t* tab, int32_t* r0, int32_t* bad,
+                     void* stream);
+int sga_ec_z_symbols(const float* z_hat, int64_t n, int num_filters, int32_t* sym, int32_t* tab, int32_t* bad,
+                     void* stream);
+int sga_ec_encode(const int32_t* sym, const int32_t* tab, int64_t n, int block, const uint32_t* cdf, const int32_t* lens,
+                  const int32_t* offs, int stride, uint8_t* slots, int slot_cap, uint32_t* block_bytes, void* stream);
+int sga_ec_compact(const uint8_t* slots, int slot_cap, const uint32_t* block_bytes, const uint64_t* block_off,
+                   int nblocks, uint8_t* out, void* stream);
+int sga_ec_decode(const uint8_t* in, const uint64_t* block_off, const uint32_t* block_bytes, int nblocks,
+                  const int32_t* tab, int64_t n, int block, const uint32_t* cdf, const int32_t* lens, const int32_t* offs,
+                  int stride, int32_t* sym, int32_t* bad, void* stream);
+
 /* ---- measurement: per-kernel hipEvent timing of the convolution launches -------------------
  * Between sga_profile_begin and sga_profile_end every MFMA convolution launch issued through
  * this handle is bracketed by a hipEvent pair on its own stream (sga_run then launches eagerly

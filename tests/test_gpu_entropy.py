@@ -1,0 +1,72 @@
+"""SURVEY.md 8(f)-4 on the device: the rANS coder of csrc/rans.hip (one lane per block of 1024 symbols) and the
+symbol / table-index kernels against the host coder (csrc_cpu/rans.c through entropy_coding.EntropyCoder) -- byte-identical
+streams for the same tables, exact decode, escapes included -- on the latents of a real SGA run at the benchmark geometry
+(mbt2018.py:84-85,211-222 is where the reference produces bytes)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import sga_amd  # noqa: E402
+from sga_amd import entropy_coding as ec  # noqa: E402
+
+
+def _codec(C, B, H, W):
+    from sga_amd.codec import SGACodec
+    return SGACodec(sga_amd.make_synthetic_weights(C, seed=0), C, B, H, W)
+
+
+def test_device_symbols_equal_the_host_rule():
+    """sym = y_hat - rint(mu), table = scale level x mean bin: sga_ec_y_symbols == EntropyCoder._y_symbols elementwise,
+    on scales below / inside / above the table and on mu at every bin boundary."""
+    codec = _codec(64, 1, 64, 64)
+    coder = codec._entropy_coder()
+    rng = np.random.RandomState(0)
+    n = 50000
+    mu = (rng.standard_normal(n) * 3).astype(np.float32)
+    mu[:64] = (np.arange(64) / 8.0 - 4.0).astype(np.float32)              # exact bin boundaries and .5 ties
+    sigma = np.exp(rng.standard_normal(n) * 2.5).astype(np.float32)
+    sigma[:200] = coder.scale_table[rng.randint(0, 64, 200)].astype(np.float32)   # on the table's levels (float32-rounded)
+    sigma[200:210] = [0.01, 0.11, 0.1099, 256.0, 300.0, 1e4, 1e-6, 0.11000001, 255.9, 1.0]
+    y = np.rint(mu + sigma * rng.standard_normal(n)).clip(-3e4, 3e4).astype(np.float32)
+    r0, tab = coder._y_symbols(y, mu, sigma)
+    out = codec._ec_symbols_device(coder, codec._t(y), codec._t(mu), codec._t(sigma), None)
+    assert int(out["bad"].item()) == 0
+    assert np.array_equal(out["y_tab"].cpu().numpy(), tab) and np.array_equal(out["r0"].cpu().numpy(), r0)
+    assert np.array_equal(out["y_sym"].cpu().numpy(), y.astype(np.int32) - r0)
+    # non-integer latents are counted, not silently coded
+    y[5] += 0.25
+    assert int(codec._ec_symbols_device(coder, codec._t(y), codec._t(mu), codec._t(sigma), None)["bad"].item()) == 1
+    codec.close()
+
+
+@pytest.mark.parametrize("C,B,H,W,its", [(64, 2, 64, 80, 30), (192, 8, 256, 256, 40)])
+def test_device_rans_bytes_equal_the_host_coder(C, B, H, W, its, gpu_out_dir):
+    codec = _codec(C, B, H, W)
+    x = np.random.RandomState(3).rand(B, H, W, 3).astype(np.float32)
+    y_hat, z_hat, met, _ = codec.run(x, 0.01, its=its, seed=2)
+    y_hat[0, 0, 0, :3] = torch.tensor([5000.0, -5000.0, 70000.0])          # escapes (outside every table)
+    z_hat[0, 0, 0, :2] = torch.tensor([400.0, -97.0])
+    dev = codec.compress_latents((B, H, W), y_hat, z_hat, on_device=True)
+    host = codec.compress_latents((B, H, W), y_hat, z_hat, on_device=False)
+    assert dev == host, (len(dev), len(host))                              # byte for byte
+    for on_device in (True, False):
+        xs, y2, z2 = codec.decompress_latents(dev, on_device=on_device)
+        assert tuple(xs) == (B, H, W) and torch.equal(y2, y_hat) and torch.equal(z2, z_hat)
+    # a flipped payload byte is either detected or decodes to other latents; a truncated stream is refused
+    bad = bytearray(dev); bad[len(bad) // 2] ^= 0x55
+    try:
+        _, y3, z3 = codec.decompress_latents(bytes(bad))
+        assert not (torch.equal(y3, y_hat) and torch.equal(z3, z_hat))
+    except ValueError:
+        pass
+    with pytest.raises(ValueError):
+        codec.decompress_latents(dev[:len(dev) // 2])
+    from sga_amd.codec import metrics_to_dict
+    est = float(metrics_to_dict(met)["est_bpp"].mean())
+    import json, os
+    with open(os.path.join(gpu_out_dir, "parity_entropy.jsonl"), "a") as f:
+        f.write(json.dumps(dict(test="device_rans", C=C, B=B, H=H, W=W, bytes=len(dev),
+                                actual_bpp=8.0 * len(dev) / (B * H * W), est_bpp_before_edits=est)) + "\n")
+    codec.close()
