@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256) void deconv3_halo_kernel(
     if (lane == 0) { red[wid] = d0; red[4 + wid] = d1; }
     __syncthreads();
     if (tid == 0) {
-      atomicAdd(&ms.sums[b].sq, red[0] + red[1] + red[2] + red[3]);
-      atomicAdd(&ms.sums[b].sq_q, red[4] + red[5] + red[6] + red[7]);
+      atomicAdd(&ms.sums[b].sq_p[blockIdx.x % kSqSlots], red[0] + red[1] + red[2] + red[3]);
+      atomicAdd(&ms.sums[b].sqq_p[blockIdx.x % kSqSlots], red[4] + red[5] + red[6] + red[7]);
     }
   }
 }

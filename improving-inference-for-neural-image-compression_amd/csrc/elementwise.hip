@@ -489,8 +489,8 @@ __global__ void k_mse(const float* __restrict__ x, const float* __restrict__ xt,
   double acc[2] = {(double)a0, (double)a1};
   block_sum<2>(acc, sh);
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[b].sq, acc[0]);
-    atomicAdd(&sums[b].sq_q, acc[1]);
+    atomicAdd(&sums[b].sq_p[blockIdx.x % kSqSlots], acc[0]);
+    atomicAdd(&sums[b].sqq_p[blockIdx.x % kSqSlots], acc[1]);
   }
 }
 
@@ -638,13 +638,13 @@ __global__ void k_check_int(const int* __restrict__ p, int expected, int* __rest
 
 __device__ __forceinline__ void finalize_step_body(ImgSums* sums, StepCtx* __restrict__ ctx, int B, int H,
                                                    int W, float* scalars, float* psnr, float* trace,
-                                                   const float* __restrict__ Ttab, const float* __restrict__ lrtab);
+                                                   const float* __restrict__ Ttab, const float* __restrict__ lrtab, int lane);
 
 __global__ void k_finalize_step(ImgSums* sums, StepCtx* __restrict__ ctx, int B, int H,
                                 int W, float* scalars, float* psnr, float* trace,
                                 const float* __restrict__ Ttab, const float* __restrict__ lrtab) {
-  if (threadIdx.x != 0) return;
-  finalize_step_body(sums, ctx, B, H, W, scalars, psnr, trace, Ttab, lrtab);
+  if (threadIdx.x >= 64) return;          // one wave, all 64 lanes: the distortion sub-accumulators are folded cooperatively
+  finalize_step_body(sums, ctx, B, H, W, scalars, psnr, trace, Ttab, lrtab, threadIdx.x);
 }
 
 // The boundary between two SGA iterations in ONE launch: Adam on (y, z) with this iteration's gradients
@@ -696,49 +696,81 @@ __global__ void k_step_boundary(float* __restrict__ py, const float* __restrict_
   if (threadIdx.x == 0)
     last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   __syncthreads();
-  if (last && threadIdx.x == 0) {
-    finalize_step_body(sums, ctx, B, H, W, nullptr, nullptr, trace, Ttab, lrtab);
-    *ticket = 0;
+  if (last && threadIdx.x < 64) {
+    finalize_step_body(sums, ctx, B, H, W, nullptr, nullptr, trace, Ttab, lrtab, threadIdx.x);
+    if (threadIdx.x == 0) *ticket = 0;
   }
 }
 
+// Called by the 64 lanes of ONE wave (uniform control flow).  The per-image distortion sub-accumulators (ImgSums::sq_p /
+// sqq_p, kSqSlots each) are loaded 4 images at a time, 16 lanes per image, folded by shuffles and zeroed; every lane then
+// runs the same scalar code and lane 0 stores.
 __device__ __forceinline__ void finalize_step_body(ImgSums* sums, StepCtx* __restrict__ ctx, int B, int H,
                                                    int W, float* scalars, float* psnr, float* trace,
-                                                   const float* __restrict__ Ttab, const float* __restrict__ lrtab) {
+                                                   const float* __restrict__ Ttab, const float* __restrict__ lrtab, int lane) {
+  static_assert(kSqSlots == 16, "16 lanes per image");
+  const bool l0 = lane == 0;
   const double npx = (double)H * W;
   const double ls = ctx->loss_scale;
   double sq = 0.0, nats = 0.0, ps = 0.0;
-  for (int b = 0; b < B; ++b) {
-    sq += sums[b].sq;
-    nats += sums[b].y_nats + sums[b].z_nats + sums[b].q_ln;     // q_ln = 0 outside bits-back
-    const double mse_q = sums[b].sq_q / (npx * 3.0);
-    const float pb = (float)(10.0 * log10(65025.0 / mse_q));
-    if (psnr) psnr[b] = pb;
-    ps += pb;
-    sums[b].sq = 0.0; sums[b].sq_q = 0.0; sums[b].y_nats = 0.0; sums[b].z_nats = 0.0;
-    sums[b].q_ln = 0.0;
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    const int bi = b0 + (lane >> 4), k = lane & 15;
+    double pa = 0.0, pc = 0.0;
+    if (bi < B) {
+      pa = sums[bi].sq_p[k]; pc = sums[bi].sqq_p[k];
+      sums[bi].sq_p[k] = 0.0; sums[bi].sqq_p[k] = 0.0;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      pa += __shfl_down(pa, o, 64);
+      pc += __shfl_down(pc, o, 64);
+    }
+    for (int j = 0; j < 4 && b0 + j < B; ++j) {
+      const int b = b0 + j;
+      const double tsq = sums[b].sq + __shfl(pa, 16 * j, 64), tsqq = sums[b].sq_q + __shfl(pc, 16 * j, 64);
+      sq += tsq;
+      nats += sums[b].y_nats + sums[b].z_nats + sums[b].q_ln;     // q_ln = 0 outside bits-back
+      const double mse_q = tsqq / (npx * 3.0);
+      const float pb = (float)(10.0 * log10(65025.0 / mse_q));
+      if (psnr && l0) psnr[b] = pb;
+      ps += pb;
+      if (l0) {
+        sums[b].sq = 0.0; sums[b].sq_q = 0.0; sums[b].y_nats = 0.0; sums[b].z_nats = 0.0;
+        sums[b].q_ln = 0.0;
+      }
+    }
   }
   const float train_mse = (float)(sq * ls / (npx * 3.0) * 65025.0);
   const float train_bpp = (float)(nats * ls / (0.6931471805599453 * npx));
   const float lam = ctx->lambda;
   const float loss = lam > 0.f ? lam * train_mse + train_bpp : train_bpp;
+  const int it0 = ctx->it, its = ctx->its;
+  if (!l0) return;
   if (scalars) { scalars[0] = loss; scalars[1] = train_mse; scalars[2] = train_bpp; }
   if (trace) {
-    float* row = trace + (size_t)ctx->it * 4;
+    float* row = trace + (size_t)it0 * 4;
     row[0] = loss; row[1] = train_mse; row[2] = train_bpp; row[3] = (float)(ps / B);
   }
   // last kernel of the iteration: set the step context of the next one (it, T = Ttab[it], lr_t =
   // lrtab[it]; sga.py:211, adam.py:40-42), so that no separate launch has to do it
   if (Ttab) {
-    const int it = ctx->it + 1;
+    const int it = it0 + 1;
     ctx->it = it;
-    if (it < ctx->its) { ctx->T = Ttab[it]; ctx->lr_t = lrtab[it]; }
+    if (it < its) { ctx->T = Ttab[it]; ctx->lr_t = lrtab[it]; }
   }
+}
+
+// the evaluation kernels (once per run): thread b folds image b's sub-accumulators in slot order
+__device__ __forceinline__ void fold_sq(ImgSums& s) {
+  double a = s.sq, c = s.sq_q;
+  for (int k = 0; k < kSqSlots; ++k) { a += s.sq_p[k]; c += s.sqq_p[k]; s.sq_p[k] = 0.0; s.sqq_p[k] = 0.0; }
+  s.sq = a; s.sq_q = c;
 }
 
 __global__ void k_finalize_eval(ImgSums* sums, int B, int H, int W, float* metrics) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  fold_sq(sums[b]);
   const double npx = (double)H * W;
   const double mse = sums[b].sq_q / (npx * 3.0);
   const double ybpp = sums[b].y_nats / (0.6931471805599453 * npx);
@@ -759,6 +791,7 @@ __global__ void k_finalize_eval(ImgSums* sums, int B, int H, int W, float* metri
 __global__ void k_finalize_eval_bb(ImgSums* sums, int B, int H, int W, float* metrics) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  fold_sq(sums[b]);
   const double npx = (double)H * W, c = 0.6931471805599453 * npx;
   const double mse = sums[b].sq_q / (npx * 3.0);
   const double ybpp = sums[b].y_nats / c, zbpp = sums[b].z_nats / c, back = -sums[b].q_ln / c;
@@ -856,7 +889,9 @@ int launch_gaussian(const float* yt, const float* ms, const StepCtx* ctx, int B,
                     int hs, int ws, int C, float inv_ln2_hw, float scale_bound, ImgSums* sums, float* g_yt,
                     float* g_ms, hipStream_t s) {
   const int n_per_img = hs * ws * C;
-  hipLaunchKernelGGL(k_gaussian, dim3(grid_for(n_per_img, 256, 512), B), dim3(256), 0, s, yt, ms,
+  // <= 32 workgroups per image: each ends in one f64 atomic on the image's y_nats, and same-address atomics
+  // serialise at ~45 ns (384 per image cost 17 us)
+  hipLaunchKernelGGL(k_gaussian, dim3(grid_for(n_per_img, 256, 32), B), dim3(256), 0, s, yt, ms,
                      ctx, h, w, hs, ws, C, inv_ln2_hw, scale_bound, sums, g_yt, g_ms);
   LAUNCH_RET();
 }

@@ -6,12 +6,18 @@
 constexpr int EB_STRIDE = 44;   // packed floats per channel of the factorized prior
 
 // per-image accumulators (double), zeroed by k_finalize after being consumed
+// The distortion sums are accumulated by thousands of workgroups (one f64 atomic pair each): 2048 workgroups adding to
+// 8 images x 2 addresses serialise at the L2 atomic unit (~45 ns per same-address atomic: 23 us of a 60-us launch), so
+// every image has kSqSlots sub-accumulators, chosen by workgroup index, that the finalize kernels fold.
+constexpr int kSqSlots = 16;
 struct ImgSums {
-  double sq;      // sum (x - x_tilde)^2                       sga.py:150
-  double sq_q;    // sum (255x - round(255 clip(x_tilde)))^2   sga.py:170-173
+  double sq;      // sum (x - x_tilde)^2                       sga.py:150       (folded from sq_p by the finalize kernels)
+  double sq_q;    // sum (255x - round(255 clip(x_tilde)))^2   sga.py:170-173   (folded from sqq_p)
   double y_nats;  // sum -ln p(y_tilde | z_tilde)              sga.py:144
   double z_nats;  // sum -ln p(z_tilde)                        sga.py:145
   double q_ln;    // sum  ln q(z_tilde | y)  (bits-back)        bb_sga.py:102,129-130
+  double sq_p[kSqSlots];
+  double sqq_p[kSqSlots];
 };
 
 // SGA relaxation sga.py:86-98 / :111-121 (+ tfp RelaxedOneHotCategorical.sample).
@@ -46,6 +52,11 @@ int launch_gaussian_op(const float* y, const float* mu, const float* sraw, int64
 int launch_deconv3_halo_mse(const float* in, const float* w, const float* bias, float* out, int B,
                             int Hi, int Wi, int C, int Ho, int Wo, const float* x, const StepCtx* ctx,
                             ImgSums* sums, float* gpad, int Hp, int Wp, hipStream_t stream);
+// the same layer as a plain GEMM (P = in . W, 80 columns per input pixel) + col2im with the distortion in it
+// (deconv3_gemm.hip); x != null: step (sums, gpad as launch_deconv3_halo_mse)
+int launch_deconv3_gemm(const float* in, const float* w80, float* P, int B, int Hi, int Wi, int C, hipStream_t s);
+int launch_deconv3_col2im(const float* P, const float* bias, float* out, int B, int Hi, int Wi, int Ho, int Wo,
+                          const float* x, const StepCtx* ctx, ImgSums* sums, float* gpad, int Hp, int Wp, hipStream_t s);
 int launch_mse(const float* x, const float* xt, const StepCtx* ctx, int B, int H, int W, int Hp,
                int Wp, ImgSums* sums, float* gpad, float* xq_out, hipStream_t s);
 

@@ -87,6 +87,9 @@ struct sga_handle {
   bool fused_boundary = true;      // SGA_FUSED_BOUNDARY=0: Adam, relaxation and finalize as three launches
   float* gs3_halo_w = nullptr;   // C->3 layer packed for deconv3.hip: [C/32][9][16][32]
   bool gs3_generic = false;      // SGA_GS3_GENERIC=1: use the generic gather-GEMM for the C->3 layer
+  float* gs3_w80 = nullptr;      // the same layer for deconv3_gemm.hip: [80][C], row (ky*5+kx)*3 + c
+  Buf p3;                        // its product matrix P [B * 8yh * 8yw][80]
+  bool gs3_gemm = false;         // SGA_GS3_GEMM=1: GEMM + col2im (deconv3_gemm.hip) instead of the halo-tiled kernel (deconv3.hip)
   std::vector<void*> owned;      // every hipMalloc'd block
 
   // ---- workspace ----
@@ -834,16 +837,26 @@ int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float*
 int deconv_to3(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int B,
                int Hi, int Wi, int Ho, int Wo, float* out, hipStream_t st, const float* mse_x = nullptr,
                int Hp = 0, int Wp = 0, bool* mse_done = nullptr) {
+  const bool gemm = h->gs3_gemm && !h->gs3_generic && pc.Kc % 64 == 0 && pc.Kc <= 384 &&
+                    (size_t)B * Hi * Wi * 80 <= h->p3.cap;
   if (!h->gs3_generic) {
     sga_handle::ProfRec r;
     if (h->profiling) {
       r.flops = 2.0 * B * Hi * Wi * 25.0 * pc.Kc * 3.0;
-      snprintf(r.name, sizeof(r.name), h->profile_by_layer ? "%s deconv3_halo_kernel" : "deconv3_halo_kernel", h->cur_tag);
+      const char* kn = gemm ? "deconv3_gemm+col2im" : "deconv3_halo_kernel";
+      if (h->profile_by_layer) snprintf(r.name, sizeof(r.name), "%s %s", h->cur_tag, kn);
+      else snprintf(r.name, sizeof(r.name), "%s", kn);
       HIPCHK(h, hipEventCreate(&r.a));
       HIPCHK(h, hipEventCreate(&r.b));
       HIPCHK(h, hipEventRecord(r.a, st));
     }
-    if (mse_x && h->fused_mse) {
+    if (gemm) {
+      const bool fuse = mse_x && h->fused_mse;
+      HIPCHK(h, launch_deconv3_gemm(in, h->gs3_w80, h->p3.p, B, Hi, Wi, pc.Kc, st));
+      HIPCHK(h, launch_deconv3_col2im(h->p3.p, bias, out, B, Hi, Wi, Ho, Wo, fuse ? mse_x : nullptr, h->ctx, h->sums,
+                                      h->gpad.p, Hp, Wp, st));
+      if (fuse) *mse_done = true;
+    } else if (mse_x && h->fused_mse) {
       HIPCHK(h, launch_deconv3_halo_mse(in, h->gs3_halo_w, bias, out, B, Hi, Wi, pc.Kc, Ho, Wo, mse_x, h->ctx,
                                         h->sums, h->gpad.p, Hp, Wp, st));
       *mse_done = true;
@@ -1229,6 +1242,18 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
             }
         }
     TRY(upload(h, &h->gs3_halo_w, hw.data(), hw.size()));
+    {
+      std::vector<float> w80((size_t)80 * C, 0.f);
+      for (int t = 0; t < 25; ++t)
+        for (int ci = 0; ci < C; ++ci)
+          for (int ch = 0; ch < 3; ++ch) w80[(size_t)(t * 3 + ch) * C + ci] = K[((size_t)t * C + ci) * 3 + ch];
+      TRY(upload(h, &h->gs3_w80, w80.data(), w80.size()));
+      // Measured at cfg 2: GEMM 40.7 us + col2im 22.4 us = 63 us alone against 75.6 us for the halo
+      // kernel, but inside the iteration the pair is 3 us SLOWER (two launches, 64 KB of LDS per 8-wave workgroup next
+      // to the hyper branch): the halo kernel stays the default, SGA_GS3_GEMM=1 selects this path.
+      const char* eg = getenv("SGA_GS3_GEMM");
+      h->gs3_gemm = eg && eg[0] == '1';
+    }
     const char* e3 = getenv("SGA_GS3_GENERIC");
     h->gs3_generic = e3 && e3[0] == '1';
   }
@@ -1297,6 +1322,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     TRY(alloc_buf(h, h->u[L], n)); TRY(alloc_buf(h, h->s[L], n)); TRY(alloc_buf(h, h->v[L], n));
   }
   TRY(alloc_buf(h, h->gA, h->u[2].cap)); TRY(alloc_buf(h, h->gB, h->u[2].cap));
+  TRY(alloc_buf(h, h->p3, B * (size_t)(8 * g.yh) * (8 * g.yw) * 80));
   if (cfg->bits_back) {
     Buf* bb2[] = {&h->zml, &h->mzml, &h->vzml, &h->g_zml};
     for (Buf* b : bb2) TRY(alloc_buf(h, *b, 2 * nz));

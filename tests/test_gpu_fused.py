@@ -137,3 +137,27 @@ def test_step_boundary_kernel_equals_the_three_launches(C, B, H, W):
     assert torch.equal(torch.round(y), a[0]) and torch.equal(torch.round(z), a[1])
     assert torch.equal(tr[:60], a[3])
     one.close(); three.close()
+
+
+@pytest.mark.parametrize("C,B,H,W", [(64, 2, 64, 64), (64, 1, 50, 70), (192, 2, 256, 256), (256, 1, 96, 80)])
+def test_gs3_as_gemm_plus_col2im_equals_the_halo_kernel(C, B, H, W):
+    """The C -> 3 transposed convolution (nn_models.py:60-63) as a plain GEMM over all 25 x 3 kernel columns + a col2im
+    kernel with the distortion in it (deconv3_gemm.hip, SGA_GS3_GEMM=1; opt-in: faster alone, not inside the iteration)
+    against the default halo-tiled kernel: the same products summed in another order -- reconstruction, gradients and
+    the distortion sums agree to float32 rounding, and ragged sizes crop identically."""
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    gemm = _codec_env("SGA_GS3_GEMM", "1", w, C, B, H, W)
+    halo = _codec_env("SGA_GS3_GEMM", "0", w, C, B, H, W)
+    x = np.random.RandomState(C + W).rand(B, H, W, 3).astype(np.float32)
+    y, z = halo.encode(x)
+    ra = gemm.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    rb = halo.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    err = float((ra["gy"] - rb["gy"]).abs().max() / rb["gy"].abs().max())
+    assert 0 < err < 1e-5, err
+    assert torch.equal(ra["gz"], rb["gz"])
+    assert ra["train_mse"] == pytest.approx(rb["train_mse"], rel=1e-6) and ra["rd_loss"] == pytest.approx(rb["rd_loss"], rel=1e-6)
+    (ma, xa), (mb, xb) = gemm.evaluate(x, torch.round(y), torch.round(z), want_x_hat=True), \
+        halo.evaluate(x, torch.round(y), torch.round(z), want_x_hat=True)
+    assert float((xa - xb).abs().max()) < 1e-5 * float(xb.abs().max())
+    assert torch.allclose(ma[:, [0, 1, 4]], mb[:, [0, 1, 4]], rtol=1e-3)
+    gemm.close(); halo.close()
