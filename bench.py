@@ -230,8 +230,12 @@ def main():
                             launches=k["launches"], traffic=None,
                             note="achieved/frac: the kernel alone on the chip (eager launches, hipEvents on its stream); "
                                  "in_graph: the same symbol inside the two-stream hipGraph replay that `value` times")
-            # the same symbol inside the graph replay (event-record nodes around its launch; 200 replays)
+            # the same symbol inside the graph replay (stamped by its own workgroups; 200 replays).  Not in the
+            # --roofline-only leg: that command is the one profiled with rocprofv3 --kernel-trace --stats, whose average
+            # for this symbol must be the eager launches' alone
             try:
+                if args.roofline_only:
+                    raise RuntimeError("skipped in --roofline-only")
                 codec.profile_graph_begin(k["name"])
                 codec.run(x, args.lmbda, its=min(args.its, 200), seed=7, metrics=False)
                 g = codec.profile_graph_end()

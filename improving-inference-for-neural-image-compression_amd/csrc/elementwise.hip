@@ -5,6 +5,8 @@
 // reference expresses as TF graph ops + tf.gradients (sga.py:86-164) is written out in closed
 // form here.  Compiled with -ffp-contract=off so the f32 arithmetic matches an unfused
 // restatement (Adam is bit-exact vs. the f32-pinned adam.py restatement).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace {
@@ -692,9 +694,21 @@ __global__ void k_step_boundary(float* __restrict__ py, const float* __restrict_
   // A workgroup takes its ticket after the barrier that follows its loop, i.e. after its context values have
   // been consumed; the relaxed device-scope atomic orders the tickets; the writes below only have to be visible
   // to the next kernel.  (A device-scope release per workgroup = an L2 write-back each: 50 us for this launch.)
+  // Two-level ticket: 512 workgroups taking ONE counter serialise at the L2 atomic unit (~45 ns per same-address
+  // atomic: the kernel ran 21 us for 5 us of work); 16 group counters (workgroup index mod 16, one cache line each)
+  // and a top counter taken by each group's last workgroup cut the longest same-address chain to 32 + 16.
   __syncthreads();
-  if (threadIdx.x == 0)
-    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  if (threadIdx.x == 0) {
+    const unsigned g = blockIdx.x & 15u;
+    const unsigned gsize = (gridDim.x >> 4) + ((gridDim.x & 15u) > g ? 1u : 0u);
+    const unsigned ngroups = gridDim.x < 16u ? gridDim.x : 16u;
+    int lastv = 0;
+    if (__hip_atomic_fetch_add(ticket + 32 * (1 + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+      ticket[32 * (1 + g)] = 0;
+      if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) lastv = 1;
+    }
+    last = lastv;
+  }
   __syncthreads();
   if (last && threadIdx.x < 64) {
     finalize_step_body(sums, ctx, B, H, W, nullptr, nullptr, trace, Ttab, lrtab, threadIdx.x);
@@ -702,49 +716,59 @@ __global__ void k_step_boundary(float* __restrict__ py, const float* __restrict_
   }
 }
 
-// Called by the 64 lanes of ONE wave (uniform control flow).  The per-image distortion sub-accumulators (ImgSums::sq_p /
-// sqq_p, kSqSlots each) are loaded 4 images at a time, 16 lanes per image, folded by shuffles and zeroed; every lane then
-// runs the same scalar code and lane 0 stores.
+// Called by the 64 lanes of ONE wave (uniform control flow).  8 images per pass, 8 lanes per image: every lane loads two of
+// the image's distortion sub-accumulators (ImgSums::sq_p / sqq_p), the image's first lane also its other sums -- ALL
+// loads of the pass are in flight together (one memory round trip; the one-thread version paid one per image, because
+// each image's loads queued behind the previous image's zeroing stores: 21 -> 14 us for the boundary kernel) -- the
+// lanes fold by shuffles, lane 0 adds the images up in index order (the f64 order of the one-thread version), and the
+// zeroing stores go out together at the end.
 __device__ __forceinline__ void finalize_step_body(ImgSums* sums, StepCtx* __restrict__ ctx, int B, int H,
                                                    int W, float* scalars, float* psnr, float* trace,
                                                    const float* __restrict__ Ttab, const float* __restrict__ lrtab, int lane) {
-  static_assert(kSqSlots == 16, "16 lanes per image");
+  static_assert(kSqSlots == 16, "two sub-accumulators per lane, 8 lanes per image");
   const bool l0 = lane == 0;
   const double npx = (double)H * W;
   const double ls = ctx->loss_scale;
+  const float lam = ctx->lambda;
+  const int it0 = ctx->it, its = ctx->its;
   double sq = 0.0, nats = 0.0, ps = 0.0;
-  for (int b0 = 0; b0 < B; b0 += 4) {
-    const int bi = b0 + (lane >> 4), k = lane & 15;
-    double pa = 0.0, pc = 0.0;
-    if (bi < B) {
-      pa = sums[bi].sq_p[k]; pc = sums[bi].sqq_p[k];
-      sums[bi].sq_p[k] = 0.0; sums[bi].sqq_p[k] = 0.0;
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    const int b = b0 + (lane >> 3), k = lane & 7;
+    const bool live = b < B, first = live && k == 0;
+    double pa = 0.0, pc = 0.0, o_sq = 0.0, o_sqq = 0.0, o_nats = 0.0;
+    if (live) {
+      pa = sums[b].sq_p[k] + sums[b].sq_p[k + 8];
+      pc = sums[b].sqq_p[k] + sums[b].sqq_p[k + 8];
+    }
+    if (first) {
+      o_sq = sums[b].sq; o_sqq = sums[b].sq_q;
+      o_nats = sums[b].y_nats + sums[b].z_nats + sums[b].q_ln;     // q_ln = 0 outside bits-back
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
+    for (int o = 4; o > 0; o >>= 1) {
       pa += __shfl_down(pa, o, 64);
       pc += __shfl_down(pc, o, 64);
     }
-    for (int j = 0; j < 4 && b0 + j < B; ++j) {
-      const int b = b0 + j;
-      const double tsq = sums[b].sq + __shfl(pa, 16 * j, 64), tsqq = sums[b].sq_q + __shfl(pc, 16 * j, 64);
-      sq += tsq;
-      nats += sums[b].y_nats + sums[b].z_nats + sums[b].q_ln;     // q_ln = 0 outside bits-back
-      const double mse_q = tsqq / (npx * 3.0);
-      const float pb = (float)(10.0 * log10(65025.0 / mse_q));
-      if (psnr && l0) psnr[b] = pb;
-      ps += pb;
-      if (l0) {
-        sums[b].sq = 0.0; sums[b].sq_q = 0.0; sums[b].y_nats = 0.0; sums[b].z_nats = 0.0;
-        sums[b].q_ln = 0.0;
-      }
+    // the image's first lane: its totals and PSNR (sga.py:170-174)
+    const double tsq = o_sq + pa, tsqq = o_sqq + pc;
+    float pb = 0.f;
+    if (first) {
+      pb = (float)(10.0 * log10(65025.0 / (tsqq / (npx * 3.0))));
+      if (psnr) psnr[b] = pb;
+    }
+    for (int j = 0; j < 8 && b0 + j < B; ++j) {      // index order, every lane the same values
+      sq += __shfl(tsq, 8 * j, 64);
+      nats += __shfl(o_nats, 8 * j, 64);
+      ps += (double)__shfl(pb, 8 * j, 64);
+    }
+    if (live) { sums[b].sq_p[k] = 0.0; sums[b].sq_p[k + 8] = 0.0; sums[b].sqq_p[k] = 0.0; sums[b].sqq_p[k + 8] = 0.0; }
+    if (first) {
+      sums[b].sq = 0.0; sums[b].sq_q = 0.0; sums[b].y_nats = 0.0; sums[b].z_nats = 0.0; sums[b].q_ln = 0.0;
     }
   }
   const float train_mse = (float)(sq * ls / (npx * 3.0) * 65025.0);
   const float train_bpp = (float)(nats * ls / (0.6931471805599453 * npx));
-  const float lam = ctx->lambda;
   const float loss = lam > 0.f ? lam * train_mse + train_bpp : train_bpp;
-  const int it0 = ctx->it, its = ctx->its;
   if (!l0) return;
   if (scalars) { scalars[0] = loss; scalars[1] = train_mse; scalars[2] = train_bpp; }
   if (trace) {
@@ -989,10 +1013,11 @@ int launch_step_boundary(float* py, const float* gay, const float* gby, float* j
                          float* zt, int64_t nz, StepCtx* ctx, int mode, const int4* img_ids, int B, int H, int W,
                          ImgSums* sums, float* trace, const float* Ttab, const float* lrtab, unsigned* ticket,
                          hipStream_t s) {
-  // at most 512 workgroups: each ends with an atomic on ONE address (1632 of them serialise to 25 us), while
-  // fewer than ~400 leave the relaxation's long dependent chains (Philox, log, atanh, exp) too little parallelism
+  // at most 1024 workgroups (measured 19.7 / 16.7 / 17.3 us at 512 / 1024 / 2048 with the two-level ticket; with ONE
+  // counter 1632 workgroups serialised to 25 us); fewer than ~400 leave the relaxation's long dependent chains (Philox,
+  // log, atanh, exp) too little parallelism
   int gy = grid_for(ny), gz = grid_for(nz);
-  const int cap = 512;
+  static const int cap = getenv("SGA_BOUNDARY_CAP") ? atoi(getenv("SGA_BOUNDARY_CAP")) : 1024;
   if (gy + gz > cap) {
     gz = gz > cap / 8 ? cap / 8 : gz;
     gy = gy > cap - gz ? cap - gz : gy;

@@ -1346,8 +1346,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   TRY(alloc_buf(h, h->scratch, 8 + B * 8));
   {
     void* p = nullptr;
-    TRY(dev_alloc(h, &p, 256));
-    if (hipMemset(p, 0, 256) != hipSuccess) return fail(SGA_ERR_HIP);
+    TRY(dev_alloc(h, &p, 17 * 128));      // k_step_boundary: top counter + 16 group counters, one cache line each
+    if (hipMemset(p, 0, 17 * 128) != hipSuccess) return fail(SGA_ERR_HIP);
     h->ticket = (unsigned*)p;
   }
   {
