@@ -301,7 +301,9 @@ def parse_args(argv):
     c = sub.add_parser("compress")
     c.add_argument("--results_dir", default="./results")
     c.add_argument("--lambda", type=float, default=-1, dest="lmbda")
-    c.add_argument("--sga_its", type=int, default=2000)
+    c.add_argument("--sga_its", type=int, default=2000,
+                   help="number of SGA iterations.  DELIBERATE DEVIATION: the reference parses this flag and then ignores "
+                        "it (sga.py:191-192 hard-codes 2000); here it is honoured -- leave it at 2000 to mirror the reference")
     c.add_argument("--annealing_rate", type=float, default=1e-3)
     c.add_argument("--t0", type=int, default=700)
     c.add_argument("--method", default="sga", choices=["sga", "bb_sga", "mbt2018", "danneal", "unoise", "ste", "map"],
