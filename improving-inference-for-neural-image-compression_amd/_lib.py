@@ -85,6 +85,7 @@ SYMBOLS["sga_bb_step_grads"] = (_I, [_P, _P, _I, _I, _I, _P, _P, _F, _F, _F, C.c
                                      _P, _P, _I, _P, _P, _P, _P, _P])
 SYMBOLS["sga_bb_run"] = (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _I, _D, _D, _D, _I, _D, C.c_uint64,
                               _P, _P, _P, _P, _P, _P])
+SYMBOLS["sga_bb_refine"] = (_I, [_P, _P, _I, _I, _I, _F, _I, _D, C.c_uint64, _P, _P])
 SYMBOLS["sga_bb_eval"] = (_I, [_P, _P, _I, _I, _I, _P, _P, _P, C.c_uint64, _P, _P])
 SYMBOLS["sga_op_factorized_density"] = (_I, [_P, _P, _I64, _P, _P, _P])
 SYMBOLS["sga_set_relaxation"] = (_I, [_P, _I, _I])

@@ -346,6 +346,21 @@ class SGACodec:
         self._exit()
         return y_hat, zml, met, (tr1[:its] if trace else None), (tr2[:r_its] if trace else None)
 
+    def bb_refine(self, y_hat, H, W, r_its=2000, r_lr=0.003, seed=0, loss_scale=None):
+        """bb_sga.py:238-261 alone: y_hat -> refined (z_mean | z_logvar), exactly the stage 2 of bb_run (same kernels, same
+        noise): what a receiver that has decoded y_hat runs to recover the sender's posterior."""
+        y_hat = self._t(y_hat)
+        B = y_hat.shape[0]
+        yh, yw, zh, zw = self.latent_shape(H, W)
+        if loss_scale is None:
+            loss_scale = 1.0 / B
+        zml = self._empty(B, zh, zw, 2 * self.C)
+        s = self._enter()
+        self._chk(self.lib.sga_bb_refine(self.handle, _ptr(y_hat), B, int(H), int(W), float(loss_scale), int(r_its),
+                                         float(r_lr), int(seed), _ptr(zml), s), "sga_bb_refine")
+        self._exit()
+        return zml
+
     def bb_evaluate(self, x, y_hat, zml, eps=None, seed=0):
         x = self._t(x)
         B, H, W, ys, zs = self._shapes(x)

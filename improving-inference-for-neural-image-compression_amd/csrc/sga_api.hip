@@ -2183,6 +2183,28 @@ int bb_iterations(sga_handle* h, int stage, const Geom& g, int n, hipStream_t st
   return SGA_OK;
 }
 
+// bb_sga.py:238-261 given y_hat in h->yt: (z_mean | z_logvar) = h_a(y_hat) (:247), fresh Adam, r_its rate-only
+// iterations with the step sizes of h->lrtab2 (uploaded by the caller).  A pure function of (y_hat, seed, r_its, r_lr,
+// loss_scale): the sender (sga_bb_run) and a receiver that has decoded y_hat (sga_bb_refine) get the same posterior
+// parameters bit for bit -- what bits-back coding needs.
+int bb_stage2(sga_handle* h, const Geom& g, int r_its, float loss_scale, uint64_t seed, hipStream_t st) {
+  const int B = g.B, H = g.H, W = g.W;
+  const int64_t nz2 = (int64_t)B * g.zh * g.zw * h->C * 2;
+  SGACHK(bb_init_z_impl(h, g, h->yt.p, h->zml.p, st));       // bb_sga.py:247
+  HIPCHK(h, launch_fill(h->mzml.p, 0.f, (int64_t)(nz2), st));
+  HIPCHK(h, launch_fill(h->vzml.p, 0.f, (int64_t)(nz2), st));
+  HIPCHK(h, launch_fill((float*)h->sums, 0.f, (int64_t)(sizeof(ImgSums) / sizeof(float)) * (B), st));
+  HIPCHK(h, launch_set_ctx(h->ctx, -1, r_its, 1.f, 0.f, 0.f, loss_scale, seed, st));
+  SGACHK(bb_iterations(h, 1, g, r_its, st, [&]() -> int {
+    HIPCHK(h, launch_advance_ctx(h->ctx, h->Ttab.p, h->lrtab2.p, st));
+    SGACHK(bb_step_core(h, g, nullptr, h->yt.p, h->zml.p, nullptr, nullptr, true, 2, st));
+    HIPCHK(h, launch_adam_ctx(h->zml.p, h->g_zml.p, h->mzml.p, h->vzml.p, nz2, h->ctx, st));
+    HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, nullptr, nullptr, h->trace.p, st));
+    return SGA_OK;
+  }));
+  return SGA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2279,17 +2301,7 @@ int sga_bb_run(sga_handle* h, const float* x, int B, int H, int W, float lambda,
   // ---- stage 2: fix y_tilde = round(y), rate optimisation of zml (bb_sga.py:238-261) ----------
   HIPCHK(h, launch_round(h->y.p, h->yt.p, ny, st));          // h->yt holds y_hat from here on
   if (y_hat) HIPCHK(h, launch_copy(y_hat, h->yt.p, (int64_t)(ny), st));
-  SGACHK(bb_init_z_impl(h, g, h->yt.p, h->zml.p, st));       // bb_sga.py:247
-  HIPCHK(h, launch_fill(h->mzml.p, 0.f, (int64_t)(nz2), st));
-  HIPCHK(h, launch_fill(h->vzml.p, 0.f, (int64_t)(nz2), st));
-  HIPCHK(h, launch_set_ctx(h->ctx, -1, r_its, 1.f, 0.f, 0.f, loss_scale, seed, st));
-  SGACHK(bb_iterations(h, 1, g, r_its, st, [&]() -> int {
-    HIPCHK(h, launch_advance_ctx(h->ctx, h->Ttab.p, h->lrtab2.p, st));
-    SGACHK(bb_step_core(h, g, nullptr, h->yt.p, h->zml.p, nullptr, nullptr, true, 2, st));
-    HIPCHK(h, launch_adam_ctx(h->zml.p, h->g_zml.p, h->mzml.p, h->vzml.p, nz2, h->ctx, st));
-    HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, nullptr, nullptr, h->trace.p, st));
-    return SGA_OK;
-  }));
+  SGACHK(bb_stage2(h, g, r_its, loss_scale, seed, st));
   if (trace2 && r_its > 0)
     HIPCHK(h, launch_copy(trace2, h->trace.p, (int64_t)((size_t)r_its * 4), st));
   if (zml_out) HIPCHK(h, launch_copy(zml_out, h->zml.p, (int64_t)(nz2), st));
@@ -2298,6 +2310,29 @@ int sga_bb_run(sga_handle* h, const float* x, int B, int H, int W, float lambda,
     HIPCHK(h, launch_set_ctx(h->ctx, 0, 0, 1.f, 0.f, 0.f, 1.f, seed, st));
     SGACHK(bb_eval_impl(h, g, h->xin.p, h->yt.p, h->zml.p, nullptr, metrics, st));
   }
+  return SGA_OK;
+}
+
+int sga_bb_refine(sga_handle* h, const float* y_hat, int B, int H, int W, float loss_scale, int r_its, double r_lr,
+                  uint64_t seed, float* zml_out, void* stream) {
+  if (!h || !y_hat || !zml_out || r_its < 0 || r_its > kMaxIts) return SGA_ERR_BAD_ARG;
+  if (!h->cfg.bits_back) return SGA_ERR_UNSUPPORTED;
+  SGACHK(check_shape(h, B, H, W));
+  hipStream_t st = (hipStream_t)stream;
+  const Geom g = make_geom(B, H, W);
+  const int64_t ny = (int64_t)B * g.yh * g.yw * h->C, nz2 = (int64_t)B * g.zh * g.zw * h->C * 2;
+  h->hT.assign(r_its > 0 ? r_its : 1, 1.f);
+  std::vector<float> lr2(r_its > 0 ? r_its : 1, 0.f);
+  for (int it = 0; it < r_its; ++it) {
+    const int t = it + 1;
+    lr2[it] = (float)(r_lr * (std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t))));
+  }
+  HIPCHK(h, hipMemcpyAsync(h->Ttab.p, h->hT.data(), h->hT.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(h->lrtab2.p, lr2.data(), lr2.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, launch_copy(h->yt.p, y_hat, ny, st));
+  SGACHK(bb_stage2(h, g, r_its, loss_scale, seed, st));
+  HIPCHK(h, launch_copy(zml_out, h->zml.p, nz2, st));
   return SGA_OK;
 }
 

@@ -118,3 +118,72 @@ int rans_decode_blocked(const uint8_t* in, const uint32_t* block_bytes, size_t n
   }
   return 0;
 }
+
+/* ---- stack coder for bits-back (bb_sga.py:133-139 estimates a refund; this is the coder that earns it) ----------
+ * rANS is a STACK: what `put` pushes, `get` pops, exactly inverse.  Bits-back coding interleaves the two on one stack:
+ * pop z under q(z | y) (the bits "got back"), push y under p(y | z), push z under the prior.  State x and a byte stack
+ * whose top is buf[*len - 1].  Symbols / tables as in rans_encode; push takes the symbols in REVERSE so that a later
+ * pop with the same tables returns them in forward order. */
+static inline int spush(uint32_t* x, uint8_t* buf, size_t cap, size_t* len, uint32_t start, uint32_t freq) {
+  const uint32_t x_max = ((RANS_L >> SCALE_BITS) << 8) * freq;
+  uint32_t v = *x;
+  while (v >= x_max) {
+    if (*len >= cap) return -1;
+    buf[(*len)++] = (uint8_t)(v & 0xff);
+    v >>= 8;
+  }
+  *x = ((v / freq) << SCALE_BITS) + (v % freq) + start;
+  return 0;
+}
+
+int rans_stack_push(uint32_t* x, uint8_t* buf, size_t cap, size_t* len, const int32_t* sym, const int32_t* tab, size_t n,
+                    const uint32_t* cdf, const int32_t* lens, const int32_t* offs, int stride) {
+  for (size_t k = n; k-- > 0;) {
+    const int t = tab[k];
+    const uint32_t* c = cdf + (size_t)t * stride;
+    const int len_t = lens[t];
+    const int32_t idx = sym[k] - offs[t];
+    if (idx >= 0 && idx < len_t - 1) {
+      if (spush(x, buf, cap, len, c[idx], c[idx + 1] - c[idx])) return -1;
+    } else {
+      const uint32_t z = ((uint32_t)sym[k] << 1) ^ (uint32_t)(sym[k] >> 31);
+      if (spush(x, buf, cap, len, z >> 16, 1) || spush(x, buf, cap, len, z & 0xffff, 1) ||
+          spush(x, buf, cap, len, c[len_t - 1], c[len_t] - c[len_t - 1]))
+        return -1;
+    }
+  }
+  return 0;
+}
+
+static inline void srenorm(uint32_t* x, const uint8_t* buf, size_t* len) {
+  while (*x < RANS_L && *len > 0) *x = (*x << 8) | buf[--(*len)];
+}
+
+/* returns 0, or -1 on a corrupt table / -2 when the stack runs dry (not enough initial bits to sample from) */
+int rans_stack_pop(uint32_t* x, const uint8_t* buf, size_t* len, const int32_t* tab, size_t n, const uint32_t* cdf,
+                   const int32_t* lens, const int32_t* offs, int stride, int32_t* sym) {
+  for (size_t k = 0; k < n; ++k) {
+    const int t = tab[k];
+    const uint32_t* c = cdf + (size_t)t * stride;
+    const int len_t = lens[t];
+    if (*x < RANS_L) return -2;
+    const uint32_t s = *x & 0xffff;
+    int lo = 0, hi = len_t;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (c[mid] <= s) lo = mid; else hi = mid; }
+    const uint32_t start = c[lo], freq = c[lo + 1] - c[lo];
+    if (freq == 0) return -1;
+    *x = freq * (*x >> SCALE_BITS) + s - start;
+    srenorm(x, buf, len);
+    if (lo < len_t - 1) {
+      sym[k] = offs[t] + lo;
+    } else {
+      if (*x < RANS_L) return -2;
+      const uint32_t zl = *x & 0xffff; *x >>= SCALE_BITS; srenorm(x, buf, len);
+      if (*x < RANS_L) return -2;
+      const uint32_t zh = *x & 0xffff; *x >>= SCALE_BITS; srenorm(x, buf, len);
+      const uint32_t z = (zh << 16) | zl;
+      sym[k] = (int32_t)((z >> 1) ^ (uint32_t)(-(int32_t)(z & 1)));
+    }
+  }
+  return 0;
+}

@@ -87,9 +87,10 @@ def _ptr(a, t):
 # ---------------------------------------------------------------------------------------------
 # probability models (numpy, float64) -> quantised CDF tables
 # ---------------------------------------------------------------------------------------------
-def factorized_mass(w: dict, ks: np.ndarray) -> np.ndarray:
-    """p_c(k) for integer grid ks [K] and every channel: returns [K, C] (learned_prior.py:96-121 +
-    the box mass with the sign trick of tfc EntropyBottleneck._likelihood)."""
+def factorized_mass(w: dict, ks: np.ndarray, half: float = 0.5) -> np.ndarray:
+    """p_c(k) for grid points ks [K] and every channel: the mass of [k - half, k + half], returns [K, C]
+    (learned_prior.py:96-121 + the box mass with the sign trick of tfc EntropyBottleneck._likelihood; half = 0.5: the
+    integer bins of z_hat, smaller: the fine grid of bits_back.py)."""
     Cn = w["eb.m0"].shape[0]
 
     def logits(v):                       # v [K] -> [K, C]
@@ -100,7 +101,7 @@ def factorized_mass(w: dict, ks: np.ndarray) -> np.ndarray:
                 t = t + w[f"eb.f{k}"].astype(np.float64) * np.tanh(t)
         return t[:, 0, :].T
 
-    lo, up = logits(ks - 0.5), logits(ks + 0.5)
+    lo, up = logits(ks - half), logits(ks + half)
     sg = -np.sign(lo + up)
     sig = lambda x: 1.0 / (1.0 + np.exp(-x))
     return np.abs(sig(sg * up) - sig(sg * lo))

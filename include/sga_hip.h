@@ -222,6 +222,11 @@ int sga_bb_run(sga_handle* h, const float* x, int B, int H, int W, float lambda,
                int its, int r_its, double lr, double r_lr, double annealing_rate, int t0,
                double T_ub, uint64_t seed, float* y_hat, float* zml_out, float* metrics,
                float* trace1, float* trace2, void* stream);
+/* bb_sga.py:238-261 alone: from y_hat (device, [B,yh,yw,C]) to the refined posterior parameters zml -- exactly the
+ * stage 2 that sga_bb_run performs, as a pure function of (y_hat, seed, r_its, r_lr, loss_scale).  A receiver that has
+ * decoded y_hat obtains the sender's q(z | y) bit for bit this way, which is what bits-back coding of z needs. */
+int sga_bb_refine(sga_handle* h, const float* y_hat, int B, int H, int W, float loss_scale, int r_its, double r_lr,
+                  uint64_t seed, float* zml_out, void* stream);
 /* bb_sga.py:273-275: eval at (y_hat, zml) with one eps draw */
 int sga_bb_eval(sga_handle* h, const float* x, int B, int H, int W, const float* y_hat,
                 const float* zml, const float* eps, uint64_t seed, float* metrics, void* stream);

@@ -78,3 +78,29 @@ def test_container_and_corruption(coder):
         ec.unpack(blob[:4] + bytes([1]) + blob[5:])            # a round-2 (format 1) stream is refused
     with pytest.raises(ValueError):
         coder.decode_z(zb[:3], z.shape)
+
+
+def test_ans_stack_push_and_pop_are_inverse(coder):
+    """rANS as a stack (bits_back.AnsStack over csrc_cpu/rans.c): pop after push returns the symbols and the stack;
+    pop FIRST (sampling from the tables with the stack's bits, the bits-back move) then push restores the stack."""
+    from sga_amd.bits_back import AnsStack
+    rng = np.random.RandomState(4)
+    n = 5000
+    tab = rng.randint(coder.y_tab0, coder.cdf.shape[0], n).astype(np.int32)
+    sym = (coder.offs[tab] + rng.randint(0, 3, n) * (coder.lens[tab] - 2) // 2).astype(np.int32)
+    sym[::97] = 30000                                                   # escapes
+    init = rng.bytes(6000)
+    st = AnsStack(init, 6000 + 8 * n + 64)
+    st.push(coder, sym, tab)
+    assert st.len.value > 6000
+    assert np.array_equal(st.pop(coder, tab), sym)
+    assert st.tobytes()[4:] == init and st.x.value == 1 << 23
+    # sample first, then put the sample back
+    got = st.pop(coder, tab)
+    assert st.len.value < 6000                                          # bits were consumed
+    idx = got - coder.offs[tab]
+    assert ((idx >= 0) & (idx < coder.lens[tab])).mean() > 0.99         # samples land inside their tables
+    st.push(coder, got, tab)
+    assert st.tobytes()[4:] == init and st.x.value == 1 << 23
+    with pytest.raises(RuntimeError):
+        AnsStack(b"", 64).pop(coder, tab)                               # nothing to sample from

@@ -70,3 +70,43 @@ def test_device_rans_bytes_equal_the_host_coder(C, B, H, W, its, gpu_out_dir):
         f.write(json.dumps(dict(test="device_rans", C=C, B=B, H=H, W=W, bytes=len(dev),
                                 actual_bpp=8.0 * len(dev) / (B * H * W), est_bpp_before_edits=est)) + "\n")
     codec.close()
+
+
+def test_bits_back_coding_of_z_for_cfg5(gpu_out_dir):
+    """cfg 5 (bb_sga.py): `est_bpp_back` (bb_sga.py:133-139) is an ESTIMATE in the reference.  bits_back.BitsBackCoder
+    codes it for real on one ANS stack -- pop z_bar ~ Q(z | y), push y_hat | z_bar, push z_bar under the prior -- and the
+    receiver, who recovers the sender's posterior by running stage 2 on the decoded y_hat (sga_bb_refine, bit-identical
+    to sga_bb_run's stage 2), undoes all three: exact latents, and the stack is the sender's initial stack again.
+    The net size matches the model's estimate `est_bpp` (= y + z - back) evaluated at the z_bar that was coded."""
+    import json, os
+    from sga_amd.codec import SGACodec, metrics_to_dict
+    from sga_amd.bits_back import BitsBackCoder
+    C, B, H, W = 64, 2, 64, 64
+    w = sga_amd.make_synthetic_weights(C, seed=0, bb=True)
+    codec = SGACodec(w, C, B, H, W, bits_back=True)
+    x = np.random.RandomState(5).rand(B, H, W, 3).astype(np.float32)
+    kw = dict(r_its=40, r_lr=0.003, seed=9)
+    y_hat, zml, met, _, _ = codec.bb_run(x, 0.01, its=40, **kw)
+    assert torch.equal(codec.bb_refine(y_hat, H, W, **kw), zml)                       # the receiver's posterior == the sender's
+    bb = BitsBackCoder(codec, delta=1.0 / 8)
+    blob, info = bb.encode(y_hat, zml, seed=1)
+    y2, z_bar, rest, x_state = bb.decode(blob, H, W, **kw)
+    assert np.array_equal(y2, y_hat.cpu().numpy()) and np.array_equal(z_bar, info["z_bar"])
+    n_init = int(round((info["init_bits"] - 23.0) / 8))
+    assert rest == np.random.RandomState(1).bytes(n_init) and x_state == 1 << 23        # every borrowed bit is back
+    # the estimate at the coded z_bar: eps = (z_bar - mean) / sigma
+    zm = zml.cpu().numpy()
+    eps = (z_bar - zm[..., :C]) / np.exp(0.5 * zm[..., C:])
+    m = metrics_to_dict(codec.bb_evaluate(x, y_hat, zml, eps=eps.astype(np.float32)))
+    est_net = float(m["est_bpp"].sum()) * H * W
+    est_back = float(m["est_bpp_back"].sum()) * H * W
+    rep = dict(net_bits=info["net_bits"], est_net_bits=est_net, bits_back=info["bits_back"], y_bits=info["y_bits"],
+               z_bits=info["z_bits"], est_y_bits=float(m["est_y_bpp"].sum()) * H * W,
+               est_z_minus_back_bits=float((m["est_z_bpp"] - m["est_bpp_back"]).sum()) * H * W, est_back_bits=est_back)
+    with open(os.path.join(gpu_out_dir, "parity_entropy.jsonl"), "a") as f:
+        f.write(json.dumps(dict(test="bits_back", **rep)) + "\n")
+    assert info["bits_back"] > 0 and info["z_bits"] > info["bits_back"] * 0.5
+    assert abs(info["y_bits"] / rep["est_y_bits"] - 1) < 0.08, rep                      # table quantisation of p(y | z)
+    assert abs((info["z_bits"] - info["bits_back"]) - rep["est_z_minus_back_bits"]) < 0.08 * abs(info["z_bits"]) + 64, rep
+    assert abs(info["net_bits"] / est_net - 1) < 0.08, rep
+    codec.close()
