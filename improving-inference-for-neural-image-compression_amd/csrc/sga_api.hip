@@ -536,6 +536,7 @@ int upload_packed(sga_handle* h, PackedConv& pc, const std::vector<float>& host,
 int pack_fwd(sga_handle* h, PackedConv& pc, const float* K, int taps, int ci, int co, int epi) {
   pc.Kc = ci; pc.N = co; pc.nslab = taps;
   pc.bn = conv_pick_bn(co, epi);
+  if (pc.bn == 96 && getenv("SGA_BN96_AS_192") && getenv("SGA_BN96_AS_192")[0] == '1') pc.bn = 192;   // see pack_bwd
   pc.Npad = cdiv(co, pc.bn) * pc.bn;
   std::vector<float> w((size_t)taps * pc.Npad * ci, 0.f);
   for (int t = 0; t < taps; ++t)
@@ -549,6 +550,9 @@ int pack_fwd(sga_handle* h, PackedConv& pc, const float* K, int taps, int ci, in
 int pack_bwd(sga_handle* h, PackedConv& pc, const float* K, int taps, int ci, int co) {
   pc.Kc = co; pc.N = ci; pc.nslab = taps;
   pc.bn = conv_pick_bn(ci, EPI_BIAS);
+  // experiment (SGA_BN96_AS_192=1): N = 288 (1.5 C at C = 192) as two 192-wide tiles (a quarter of them padding) on the
+  // 64-row LDS-DMA instance instead of three 96-wide tiles on the 2-wave register-staged one
+  if (pc.bn == 96 && getenv("SGA_BN96_AS_192") && getenv("SGA_BN96_AS_192")[0] == '1') pc.bn = 192;
   pc.Npad = cdiv(ci, pc.bn) * pc.bn;
   std::vector<float> w((size_t)taps * pc.Npad * co, 0.f);
   for (int t = 0; t < taps; ++t)
