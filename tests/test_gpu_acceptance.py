@@ -128,8 +128,9 @@ def test_trace_at_the_benchmarked_geometry(gpu_out_dir):
     sga.py:216-236 logs these) of the first 300 iterations -- temperature annealing inside them -- against the oracle's
     committed trace (`full_run_oracle_cfg2trace.json`).  This is the production launch plan over hundreds of steps (IGDN
     post-phase, 256-row LDS-DMA tiles, split 256-row gs2.bwd, two-stream graph replay) while the two float32 trajectories
-    are still the same trajectory: the objective agrees to 1e-4 over the first 100 iterations and to 2e-3 at iteration 300
-    (it is 25 % lower by then), where the statistical sets can only compare end points."""
+    are still the same trajectory -- measured: rd_loss within 2.3e-6 (relative) over the first 100 iterations and 8.3e-6
+    over all 300 (it falls from 84.9 to 71.8), train_bpp within 2.5e-5 / 1.2e-4, mean PSNR within 5e-6 -- where the
+    statistical sets can only compare end points.  Bounds asserted: 1e-4 over the first 100 iterations, 1e-3 over all."""
     from sga_amd.codec import SGACodec
     path = os.path.join(ROOT, "tests", "golden", "full_run_oracle_cfg2trace.json")
     if not os.path.exists(path):
@@ -156,7 +157,7 @@ def test_trace_at_the_benchmarked_geometry(gpu_out_dir):
     with open(os.path.join(gpu_out_dir, "acceptance_trace_cfg2.json"), "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps(rep))
-    assert want[-1, 0] < 0.85 * want[0, 0]                          # the run really optimises over these iterations
+    assert want[-1, 0] < 0.9 * want[0, 0]                           # the run really optimises over these iterations
     assert (rel[:100, :3] < 1e-4).all(), rep
-    assert (rel[:, :3] < 2e-3).all() and (np.abs(got[:, 3] - want[:, 3]) < 0.01).all(), rep
+    assert (rel[:, :3] < 1e-3).all() and (np.abs(got[:, 3] - want[:, 3]) < 0.01).all(), rep
     codec.close()
