@@ -310,7 +310,10 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     // 8-wave workgroup per CU, and that K loop runs at 0.90 of the MFMA peak against 0.84 for two 64-row
     // workgroups per CU (in-kernel probe, profiles/r02_clock_probe.txt: 5.70 us per 256 x 192 x 32 step) --
     // more than the second slab costs: gs2.bwd at cfg 2 467 -> 448 us, iteration 1834 -> 1823 us.
-    const bool one_per_cu = h->bm256_split && a.nphase == 1 && (n256 == 128 || n256 == 256);
+    // SGA_BM256_MIN (experiment): also single-phase launches of 32 / 64 such tiles, split 8 / 4 ways
+    static const int bm256_min = getenv("SGA_BM256_MIN") ? atoi(getenv("SGA_BM256_MIN")) : 128;
+    const bool one_per_cu = h->bm256_split && a.nphase == 1 &&
+                            (n256 == 128 || n256 == 256 || (n256 >= bm256_min && (n256 == 32 || n256 == 64)));
     if (one_per_cu) bm = 256;
     else if (h->bm64_max > 0 && n128 <= h->bm64_max) bm = 64;
     else if (h->bm256 && n128 >= 1024 && !h->plan_tiles) bm = 256;
