@@ -274,6 +274,38 @@ def test_run_short_vs_oracle(graph, precision, gpu_out_dir, monkeypatch):
     codec.close()
 
 
+def test_run_trace_with_more_than_eight_images(gpu_out_dir):
+    """B = 11: the iteration's scalars are folded by one wave, 8 images per pass (k_step_boundary's finalize; the
+    distortion sums live in 16 sub-accumulators per image): a batch that needs two passes, the second one ragged,
+    against the oracle loop -- trace and per-image end metrics."""
+    from sga_amd.codec import SGACodec, metrics_to_dict
+    C, B, H, W = 64, 11, 32, 48
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    codec, orc = SGACodec(w, C, B, H, W), SGAOracle(w)
+    x = image(B, H, W, seed=81)
+    its = 12
+    y_hat, z_hat, met, tr = codec.run(x, 0.01, its=its, t0=4, annealing_rate=0.05, seed=3, trace=True)
+    yo, zo, mo, tro = orc.run(x, 0.01, its=its, t0=4, r=0.05, seed=3, trace=True)
+    assert np.allclose(tr.cpu().numpy()[:, :3], tro[:, :3], rtol=2e-4), np.abs(tr.cpu().numpy() / tro - 1).max(0)
+    assert np.allclose(tr.cpu().numpy()[:, 3], tro[:, 3], atol=2e-3)
+    got = metrics_to_dict(met)
+    assert np.allclose(got["est_bpp"], mo["est_bpp"], rtol=5e-3) and np.allclose(got["psnr"], mo["psnr"], atol=0.05)
+    # and through the eager three-launch boundary (k_finalize_step) the same trace bit for bit
+    import os as _os
+    old = _os.environ.get("SGA_FUSED_BOUNDARY")
+    _os.environ["SGA_FUSED_BOUNDARY"] = "0"
+    try:
+        c2 = SGACodec(w, C, B, H, W)
+    finally:
+        if old is None:
+            _os.environ.pop("SGA_FUSED_BOUNDARY")
+        else:
+            _os.environ["SGA_FUSED_BOUNDARY"] = old
+    tr2 = c2.run(x, 0.01, its=its, t0=4, annealing_rate=0.05, seed=3, trace=True)[3]
+    assert torch.equal(tr, tr2)
+    codec.close(); c2.close()
+
+
 @pytest.mark.parametrize("graph", [True, False])
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_run_deterministic(precision, graph, gpu_out_dir, monkeypatch):
