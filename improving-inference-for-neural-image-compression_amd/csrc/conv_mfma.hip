@@ -619,7 +619,9 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           float* e = cb + ((reg & 3) + 8 * (reg >> 2)) * TP + tn * 32;
-          *e = *e * sqrtf(acc2[tn][reg] + beta_c[tn]);          // v = u * s, in place
+          const float sv = sqrtf(acc2[tn][reg] + beta_c[tn]);
+          acc2[tn][reg] = sv;                                   // s replaces n in the accumulator registers
+          *e = *e * sv;                                         // v = u * s, in place
         }
       __builtin_amdgcn_wave_barrier();
       emit(a.post_v);                                // v
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
       for (int tn = 0; tn < PTN; ++tn)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
-          cb[((reg & 3) + 8 * (reg >> 2)) * TP + tn * 32] = sqrtf(acc2[tn][reg] + beta_c[tn]);   // s (recomputed: registers are short)
+          cb[((reg & 3) + 8 * (reg >> 2)) * TP + tn * 32] = acc2[tn][reg];   // s (kept where n was)
       __builtin_amdgcn_wave_barrier();
       emit(a.post_s);                                // s
       lds_barrier();                                 // the tile is rewritten by the next part
