@@ -114,8 +114,13 @@ def _acceptance(gpu_out_dir, golden, precision, tag):
     # difference of two draws (sqrt(2) sigma), and the HIP path's spread equals the oracle's
     sig_b = np.sqrt(2.0) * np.array(spread["est_bpp_std_per_image"])
     sig_p = np.sqrt(2.0) * np.array(spread["psnr_std_per_image"])
-    assert (np.abs(d_bpp) <= 5 * sig_b[None, :] + 1e-4).all(), rep
-    assert (np.abs(d_psnr) <= 5 * sig_p[None, :] + 1e-3).all(), rep
+    nsig = 5.0
+    if len(gold["runs"]) < 16:      # a per-image sigma from < 16 seeds is itself uncertain by 20-35 %: pool the images, 6 sigma
+        sig_b = np.maximum(sig_b, np.sqrt(np.mean(sig_b ** 2)))
+        sig_p = np.maximum(sig_p, np.sqrt(np.mean(sig_p ** 2)))
+        nsig = 6.0
+    assert (np.abs(d_bpp) <= nsig * sig_b[None, :] + 1e-4).all(), rep
+    assert (np.abs(d_psnr) <= nsig * sig_p[None, :] + 1e-3).all(), rep
     ratio = np.array(rep["hip_seed_std_bpp"]) / np.array(spread["est_bpp_std_per_image"])
     # (a standard deviation estimated from k seeds has a relative error of ~ 1 / sqrt(2 (k - 1)): wider bounds for the
     # 5-seed set at the benchmarked geometry)
