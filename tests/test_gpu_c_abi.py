@@ -64,3 +64,38 @@ def test_plain_c_client_matches_python_host(tmp_path):
     assert np.array_equal(out[nm:], want[nm:]), "latents from the C client differ from the Python host"
     assert np.allclose(out[:nm], want[:nm], rtol=1e-6, atol=0, equal_nan=True)
     codec.close()
+
+
+def test_error_codes_of_the_round3_entry_points():
+    """Bad arguments come back as negative sga_status codes, never as a crash or a silent no-op (include/sga_hip.h:
+    "return 0 on success, a negative sga_status on error")."""
+    import ctypes as C
+    from sga_amd import _lib
+    from sga_amd.codec import SGACodec
+    w = sga_amd.make_synthetic_weights(64, seed=0)
+    codec = SGACodec(w, 64, 2, 64, 64)
+    lib, h = codec.lib, codec.handle
+    BAD_ARG, UNSUPPORTED = -1, -3
+    assert lib.sga_set_scale_bound(h, C.c_float(-0.5)) == BAD_ARG
+    assert lib.sga_set_scale_bound(h, C.c_float(float("nan"))) == BAD_ARG
+    assert lib.sga_set_scale_bound(None, C.c_float(0.11)) == BAD_ARG
+    assert lib.sga_set_scale_bound(h, C.c_float(0.11)) == 0 and lib.sga_set_scale_bound(h, C.c_float(0.0)) == 0
+    seeds = (C.c_uint64 * 3)(1, 2, 3)
+    assert lib.sga_set_image_seeds(h, seeds, 3) == BAD_ARG            # more than max_batch
+    assert lib.sga_set_image_seeds(h, None, 1) == BAD_ARG
+    assert lib.sga_set_image_seeds(h, seeds, 2) == 0 and lib.sga_set_image_seeds(h, None, 0) == 0
+    z = torch.zeros(2, 1, 1, 128, device="cuda")
+    y = torch.zeros(2, 4, 4, 64, device="cuda")
+    assert lib.sga_bb_refine(h, C.c_void_p(y.data_ptr()), 2, 64, 64, C.c_float(0.5), 5, C.c_double(0.003), 0,
+                             C.c_void_p(z.data_ptr()), None) == UNSUPPORTED      # not a bits-back handle
+    assert lib.sga_profile_graph_begin(h, b"") == BAD_ARG
+    i32 = torch.zeros(16, dtype=torch.int32, device="cuda")
+    u8 = torch.zeros(16 * 64, dtype=torch.uint8, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.sga_ec_encode(None, p(i32), 16, 1024, p(i32), p(i32), p(i32), 4, p(u8), 64, p(i32), None) == BAD_ARG
+    assert lib.sga_ec_encode(p(i32), p(i32), 16, 1024, p(i32), p(i32), p(i32), 4, p(u8), 8, p(i32), None) == BAD_ARG   # slot too small
+    assert lib.sga_ec_decode(p(u8), p(i32), p(i32), 3, p(i32), 16, 1024, p(i32), p(i32), p(i32), 4, p(i32), p(i32), None) == BAD_ARG
+    cfg = _lib.SgaConfig(64, 1, 64, 64, 0, 0, -1.0, 0)                # negative bound in the config
+    hh = C.c_void_p(0)
+    assert lib.sga_create(C.byref(hh), C.byref(cfg), C.byref(_lib.SgaWeights())) == BAD_ARG
+    codec.close()
