@@ -626,6 +626,62 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
       __builtin_amdgcn_wave_barrier();
       emit(a.post_v);                                // v
       __builtin_amdgcn_wave_barrier();
+      // ---- the NEXT layer's products while v is on chip (C -> 3 transposed convolution, nn_models.py:60-63) ----
+      // P[pixel, (ky, kx, c)] = v[pixel, :] . W3[ky, kx, :, c] for all 25 x 3 (padded to 80) kernel columns: a third
+      // contraction out of the tile, 16 rows per wave on v_mfma_f32_16x16x4_f32 with the weights as the A operand (a lane's
+      // 4 accumulators = 16 contiguous bytes of P), W3 in K-chunks through the gamma buffers.  The layer itself then is a
+      // col2im over P (deconv3_gemm.hip) and never reads v.  Same MFMA sequence as deconv3_gemm_kernel: bit-equal P.
+      // POST = 2 only: a separate instance, because the code's mere presence costs the plain post-phase 11 spilled
+      // VGPRs (3663 vs 3620 ms per batch when compiled in and unused)
+      if constexpr (HR == 128 && POST == 2) {
+        if (a.post_p) {
+          lds_barrier();                             // every wave's block of v is in the tile
+          f32x4 rw3[2];
+          auto load_w3 = [&](int kc) {               // 80 rows x 32 floats = 640 float4: threads 0..511 + 0..127
+            rw3[0] = ld4(a.post_w3 + (size_t)lrow * C + kc * 32 + chunk * 4);
+            if (tid < 128) rw3[1] = ld4(a.post_w3 + (size_t)(64 + lrow) * C + kc * 32 + chunk * 4);
+          };
+          auto store_w3 = [&](int buf) {
+            *reinterpret_cast<f32x4*>(&Bq[buf * (C * LDK) + lrow * LDK + chunk * 4]) = rw3[0];
+            if (tid < 128) *reinterpret_cast<f32x4*>(&Bq[buf * (C * LDK) + (64 + lrow) * LDK + chunk * 4]) = rw3[1];
+          };
+          typedef float f32x4v __attribute__((ext_vector_type(4)));
+          f32x4v acc3[5];
+#pragma unroll
+          for (int c5 = 0; c5 < 5; ++c5) acc3[c5] = f32x4v{0.f, 0.f, 0.f, 0.f};
+          const int li16 = lane & 15, g4 = lane >> 4;
+          load_w3(0);
+          store_w3(0);
+          load_w3(1);
+          lds_barrier();
+#pragma unroll
+          for (int kc = 0; kc < C / 32; ++kc) {
+            if (kc + 1 < C / 32) store_w3((kc + 1) & 1);
+            if (kc + 2 < C / 32) load_w3(kc + 2);
+            const float* W3s = Bq + (kc & 1) * (C * LDK);
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+              const f32x4 vf = *reinterpret_cast<const f32x4*>(&Tt[(wid * 16 + li16) * TP + kc * 32 + q2 * 16 + g4 * 4]);
+              f32x4 wf[5];
+#pragma unroll
+              for (int c5 = 0; c5 < 5; ++c5)
+                wf[c5] = *reinterpret_cast<const f32x4*>(&W3s[(c5 * 16 + li16) * LDK + q2 * 16 + g4 * 4]);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c5 = 0; c5 < 5; ++c5)
+                  acc3[c5] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c5][r], vf[r], acc3[c5], 0, 0, 0);
+            }
+            lds_barrier();
+          }
+          const long long pxp = rowpix[h * HR + wid * 16 + li16];
+          if (pxp >= 0) {
+#pragma unroll
+            for (int c5 = 0; c5 < 5; ++c5)
+              *reinterpret_cast<f32x4v*>(a.post_p + (size_t)pxp * 80 + c5 * 16 + 4 * g4) = acc3[c5];
+          }
+        }
+      }
 #pragma unroll
       for (int tn = 0; tn < PTN; ++tn)
 #pragma unroll
@@ -857,7 +913,8 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
   if (a.bm == 256) wm = 4;
   if (a.bm == 64) tm = 1;
   snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%s,%d>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
-           a.smallc ? "true" : "false", (a.x3 && !a.smallc && bn != 32) ? "true" : "false", a.post ? 1 : 0);
+           a.smallc ? "true" : "false", (a.x3 && !a.smallc && bn != 32) ? "true" : "false",
+           a.post ? (a.post_p ? 2 : 1) : 0);
 }
 
 int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream) {
@@ -889,6 +946,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
         if (a.post) {
           if (a.ksplit > 1 || a.epi != EPI_BIAS || a.Cout != 192 || a.out_coff != 0 || a.out_cs != 192)
             return (int)hipErrorInvalidValue;
+          if (a.post_p) return launch_inst<2, 3, 4, 2, PRO_NONE, false, false, 2>(a, stream);
           return launch_inst<2, 3, 4, 2, PRO_NONE, false, false, 1>(a, stream);
         }
         return launch_inst<2, 3, 4, 2, PRO_NONE, false>(a, stream);

@@ -90,6 +90,8 @@ struct sga_handle {
   float* gs3_w80 = nullptr;      // the same layer for deconv3_gemm.hip: [80][C], row (ky*5+kx)*3 + c
   Buf p3;                        // its product matrix P [B * 8yh * 8yw][80]
   bool gs3_gemm = false;         // SGA_GS3_GEMM=1: GEMM + col2im (deconv3_gemm.hip) instead of the halo-tiled kernel (deconv3.hip)
+  bool post_p = false;           // SGA_POST_P=1 (experiment): the C -> 3 layer's products formed in the post-phase of gs2.fwd when that
+                                 //   launch fuses the IGDN (C = 192); the layer is then only the col2im kernel.  Measured: no gain.
   std::vector<void*> owned;      // every hipMalloc'd block
 
   // ---- workspace ----
@@ -286,6 +288,8 @@ struct Deferred {
 struct PostGdn {
   const float* gamma_w = nullptr; const float* beta = nullptr; float* s_out = nullptr; float* v_out = nullptr;
   bool drop_u = false;       // in: the fused launch need not write u (the backward pass uses v / s)
+  const float* w3 = nullptr; float* p3 = nullptr;      // in (optional): also form the next (C -> 3) layer's products P = v . w3
+  bool p3_done = false;      // out: the fused launch wrote P
   bool fused = false;        // out: the convolution launch did the IGDN as well
 };
 
@@ -380,6 +384,11 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     if (post->fused) {
       a.post = 1; a.post_w = post->gamma_w; a.post_beta = post->beta; a.post_s = post->s_out; a.post_v = post->v_out;
       if (post->drop_u) a.out = nullptr;
+      if (post->w3 && post->p3 && a.Cout == 192) {
+        a.post_w3 = post->w3; a.post_p = post->p3;
+        post->p3_done = true;
+        a.flops += 2.0 * a.B * a.Hout * a.Wout * 75.0 * a.Cout;      // the C -> 3 layer's useful MACs ride in this launch
+      }
       a.flops += 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cout;
     }
   }
@@ -843,14 +852,15 @@ int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float*
 // kernel is in use; otherwise the caller launches k_mse
 int deconv_to3(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int B,
                int Hi, int Wi, int Ho, int Wo, float* out, hipStream_t st, const float* mse_x = nullptr,
-               int Hp = 0, int Wp = 0, bool* mse_done = nullptr) {
-  const bool gemm = h->gs3_gemm && !h->gs3_generic && pc.Kc % 64 == 0 && pc.Kc <= 384 &&
-                    (size_t)B * Hi * Wi * 80 <= h->p3.cap;
+               int Hp = 0, int Wp = 0, bool* mse_done = nullptr, bool p_ready = false) {
+  const bool gemm = p_ready || (h->gs3_gemm && !h->gs3_generic && pc.Kc % 64 == 0 && pc.Kc <= 384 &&
+                                (size_t)B * Hi * Wi * 80 <= h->p3.cap);
   if (!h->gs3_generic) {
     sga_handle::ProfRec r;
     if (h->profiling) {
       r.flops = 2.0 * B * Hi * Wi * 25.0 * pc.Kc * 3.0;
-      const char* kn = gemm ? "deconv3_gemm+col2im" : "deconv3_halo_kernel";
+      const char* kn = p_ready ? "deconv3_col2im" : (gemm ? "deconv3_gemm+col2im" : "deconv3_halo_kernel");
+      if (p_ready) r.flops = 0.0;      // counted in the launch that formed P
       if (h->profile_by_layer) snprintf(r.name, sizeof(r.name), "%s %s", h->cur_tag, kn);
       else snprintf(r.name, sizeof(r.name), "%s", kn);
       HIPCHK(h, hipEventCreate(&r.a));
@@ -859,7 +869,7 @@ int deconv_to3(sga_handle* h, const PackedConv& pc, const float* bias, const flo
     }
     if (gemm) {
       const bool fuse = mse_x && h->fused_mse;
-      HIPCHK(h, launch_deconv3_gemm(in, h->gs3_w80, h->p3.p, B, Hi, Wi, pc.Kc, st));
+      if (!p_ready) HIPCHK(h, launch_deconv3_gemm(in, h->gs3_w80, h->p3.p, B, Hi, Wi, pc.Kc, st));
       HIPCHK(h, launch_deconv3_col2im(h->p3.p, bias, out, B, Hi, Wi, Ho, Wo, fuse ? mse_x : nullptr, h->ctx, h->sums,
                                       h->gpad.p, Hp, Wp, st));
       if (fuse) *mse_done = true;
@@ -999,6 +1009,7 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   // Layers whose tile grid under-fills the chip run split-K; their partial slabs are summed (+ bias)
   // by the IGDN kernel that follows instead of by a reduce launch (fused_gdn).
   const bool fz = h->fused_gdn;
+  bool p3_done = false;      // the C -> 3 layer's products were formed by gs2.fwd's post-phase
   // u is needed again only by the IGDN data-gradient, which can form it as v / s: with the tile kernels in use the
   // forward pass stores s and v only (gs2.fwd + IGDN writes 201 instead of 302 MB at cfg 2)
   const bool drop_u = fz && with_grad && !h->keep_u;
@@ -1007,11 +1018,16 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
     PostGdn pg;
     pg.gamma_w = h->gs_gdn_f[L].w; pg.beta = h->gs_beta[L]; pg.s_out = h->s[L].p; pg.v_out = h->v[L].p;
     pg.drop_u = drop_u;
+    if (L == 2 && h->post_p && !h->gs3_generic && (size_t)B * (2 * hh) * (2 * ww) * 80 <= h->p3.cap) {
+      pg.w3 = h->gs3_w80; pg.p3 = h->p3.p;
+    }
+    p3_done = false;
     SGACHK(tick());
     h->cur_tag = kFwd[L];
     SGACHK(deconv_fwd(h, h->gs_f[L], h->gs_bias[L], cur, B, hh, ww, h->u[L].p, EPI_BIAS, st, fz ? &d : nullptr,
                       fz ? &pg : nullptr));
     hh *= 2; ww *= 2;
+    p3_done = pg.p3_done;
     if (!pg.fused) {           // otherwise the IGDN ran as the post-phase of the convolution launch
       SGACHK(tick());
       h->cur_tag = kIgdn[L];
@@ -1023,7 +1039,7 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   h->cur_tag = "gs3.fwd";
   bool mse_done = false;     // step: the distortion sums and the gradient image come out of gs3.fwd's epilogue
   SGACHK(deconv_to3(h, h->gs_f[3], h->gs_bias[3], cur, B, hh, ww, g.H, g.W, h->xt.p, st, with_grad ? x : nullptr,
-                    g.Hp, g.Wp, &mse_done));
+                    g.Hp, g.Wp, &mse_done, p3_done));
   if (!mse_done) {
     SGACHK(tick());
     HIPCHK(h, launch_mse(x, h->xt.p, with_grad ? h->ctx : nullptr, B, g.H, g.W, g.Hp, g.Wp, h->sums,
@@ -1260,6 +1276,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
       // to the hyper branch): the halo kernel stays the default, SGA_GS3_GEMM=1 selects this path.
       const char* eg = getenv("SGA_GS3_GEMM");
       h->gs3_gemm = eg && eg[0] == '1';
+      eg = getenv("SGA_POST_P");
+      h->post_p = eg && eg[0] == '1';
     }
     const char* e3 = getenv("SGA_GS3_GENERIC");
     h->gs3_generic = e3 && e3[0] == '1';

@@ -84,6 +84,8 @@ struct ConvArgs {
   // then sums the slabs and applies the epilogue (deterministic, no atomics).
   // fused IGDN post-phase (256-row unsplit C = 192 launches): out = u, post_s = sqrt(n), post_v = u * sqrt(n)
   int post; const float* post_w; const float* post_beta; float* post_s; float* post_v;
+  // ... and, with the IGDN, the products of the layer after it (C -> 3): post_p [pixel][80] = post_v . post_w3 (or null)
+  const float* post_w3; float* post_p;
   const float* zeros;      // >= 256 bytes of zeros: what taps outside the image load (LDS-DMA instance)
 #ifdef SGA_CLOCK_PROBE     // measurement build only (make PROBE=1): keeps the production kernels and their arguments unchanged
   unsigned long long* clk; // measurement only (SGA_CLOCK_PROBE=1, else null): per workgroup, shader-clock and 100 MHz

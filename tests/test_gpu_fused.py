@@ -23,9 +23,11 @@ def _pair(C, B, H, W):
     the oracle everywhere else)."""
     from sga_amd.codec import SGACodec
     w = sga_amd.make_synthetic_weights(C, seed=0)
-    old = {k: os.environ.get(k) for k in ("SGA_FUSED_GDN", "SGA_KEEP_U")}
+    old = {k: os.environ.get(k) for k in ("SGA_FUSED_GDN", "SGA_KEEP_U", "SGA_POST_P")}
     try:
-        os.environ["SGA_FUSED_GDN"] = "1"; os.environ["SGA_KEEP_U"] = "1"
+        # (SGA_POST_P=0: the C -> 3 layer by the halo kernel on both sides; its products formed in the post-phase are
+        # compared with the stand-alone GEMM in test_post_phase_products_equal_the_standalone_gemm)
+        os.environ["SGA_FUSED_GDN"] = "1"; os.environ["SGA_KEEP_U"] = "1"; os.environ["SGA_POST_P"] = "0"
         fused = SGACodec(w, C, B, H, W)
         os.environ["SGA_FUSED_GDN"] = "0"
         legacy = SGACodec(w, C, B, H, W)
@@ -161,3 +163,38 @@ def test_gs3_as_gemm_plus_col2im_equals_the_halo_kernel(C, B, H, W):
     assert float((xa - xb).abs().max()) < 1e-5 * float(xb.abs().max())
     assert torch.allclose(ma[:, [0, 1, 4]], mb[:, [0, 1, 4]], rtol=1e-3)
     gemm.close(); halo.close()
+
+
+# (shapes whose gs2.fwd the planner runs as unsplit 256-row tiles with the post-phase; 512 x 490: ragged, cropped output)
+@pytest.mark.parametrize("C,B,H,W", [(192, 2, 512, 512), (192, 4, 512, 490), (192, 8, 256, 256)])
+def test_post_phase_products_equal_the_standalone_gemm(C, B, H, W):
+    """SGA_POST_P=1 (opt-in experiment, DESIGN_EXPERIMENTS.md A.6: no gain in the iteration): at C = 192, when gs2.fwd
+    fuses the IGDN, its post-phase also forms the C -> 3 layer's products P = v . W3 (nn_models.py:60-63) while v is on
+    chip, and the layer is only the col2im kernel.  Against the same layer with P from the stand-alone GEMM
+    (SGA_GS3_GEMM=1): the same MFMA sequence, so the step, a short run and the evaluation agree BIT FOR BIT."""
+    from sga_amd.codec import SGACodec
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    old = {k: os.environ.get(k) for k in ("SGA_POST_P", "SGA_GS3_GEMM")}
+    try:
+        os.environ["SGA_POST_P"] = "1"; os.environ.pop("SGA_GS3_GEMM", None)
+        ships = SGACodec(w, C, B, H, W)
+        os.environ["SGA_POST_P"] = "0"; os.environ["SGA_GS3_GEMM"] = "1"
+        ref = SGACodec(w, C, B, H, W)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    x = np.random.RandomState(C + H).rand(B, H, W, 3).astype(np.float32)
+    y, z = ships.encode(x)
+    ra = ships.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    rb = ref.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    assert torch.equal(ra["gy"], rb["gy"]) and torch.equal(ra["gz"], rb["gz"]) and float(ra["gy"].abs().max()) > 0
+    assert ra["train_mse"] == pytest.approx(rb["train_mse"], rel=1e-6)
+    a, b = ships.run(x, 0.01, its=10, seed=1), ref.run(x, 0.01, its=10, seed=1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.allclose(a[2][:, [0, 1, 4, 5, 6]], b[2][:, [0, 1, 4, 5, 6]], rtol=1e-6, atol=0)
+    (ma, xa), (mb, xb) = ships.evaluate(x, a[0], a[1], want_x_hat=True), ref.evaluate(x, a[0], a[1], want_x_hat=True)
+    assert torch.equal(xa, xb)
+    ships.close(); ref.close()
