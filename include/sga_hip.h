@@ -70,7 +70,7 @@ typedef struct sga_config {
  *                                 bounded below by scale_table[0] = SCALES_MIN = 0.11 (mbt2018.py:30-32,77).  Set this
  *                                 for sga_base_compress.
  * PROVISIONAL: stated from tfc 1.3's source as remembered, not from a run (TF 1.15 / tfc 1.3 are not installable in the
- * build container); INTEGRATION.md section 5 has the two-line check for a TF box.  Both modes are parity-tested. */
+ * build container); INTEGRATION.md section 3c has the two-line check for a TF box.  Both modes are parity-tested. */
 #define SGA_SCALE_BOUND_NONE 0.0f
 #define SGA_SCALE_BOUND_BUILT 0.11f
 
