@@ -117,7 +117,7 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("SGA_LIB") or LIB_PATH      # SGA_LIB: A/B of two builds (scripts/ab_iter.py)
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} not found: the HIP extension is not built. Run `python -c 'import "

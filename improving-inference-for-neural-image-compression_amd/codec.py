@@ -13,6 +13,7 @@ Reference interaction                                              -> method
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -52,7 +53,8 @@ class SGACodec:
         self.max_batch, self.max_height, self.max_width = int(max_batch), int(max_height), int(max_width)
         torch.cuda.set_device(self.device)
         # a dedicated non-null stream: hipGraph capture is not allowed on the legacy null stream
-        self.stream = torch.cuda.Stream(device=self.device)
+        # (SGA_MAIN_PRIORITY: experiment switch, scripts/side_priority.py)
+        self.stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("SGA_MAIN_PRIORITY", "0")))
         self.precision = precision
         self.scale_bound = float(scale_bound)
         cfg = _lib.SgaConfig(self.C, self.max_batch, self.max_height, self.max_width, int(bits_back),

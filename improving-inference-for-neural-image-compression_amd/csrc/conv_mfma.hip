@@ -149,8 +149,17 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   } else {
     nt = bid % a.ntiles_n;
     bid /= a.ntiles_n;
-    phase = bid / a.tiles_per_phase;
-    mt = bid - phase * a.tiles_per_phase;
+    if (a.xcd_remap) {
+      // blocks b, b + 8, b + 16, ... run on XCD b % 8 (observed dispatch rule; speed only): give that XCD the M tiles
+      // [x * T/8, (x + 1) * T/8) of every phase -- at cfg 2 exactly one image -- so that the 25 tap gathers of an input
+      // region are served by one L2 instead of eight
+      const int x = bid & 7, idx = bid >> 3, tpx = a.tiles_per_phase >> 3;
+      phase = idx / tpx;
+      mt = x * tpx + (idx - phase * tpx);
+    } else {
+      phase = bid / a.tiles_per_phase;
+      mt = bid - phase * a.tiles_per_phase;
+    }
     // the 4 sub-pixel phases of a transposed conv have 9/6/6/4 taps: walk them in the order 9,6,4,6 so that
     // the workgroups that land on one CU together (block b and b + #CUs when the whole grid is resident at
     // once) are a heavy and a light phase (78 / 72 K-steps per CU instead of 90 / 60).  Only then: a grid

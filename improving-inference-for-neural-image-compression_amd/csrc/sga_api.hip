@@ -128,6 +128,7 @@ struct sga_handle {
   int dbg_it = -1;                 // iteration being enqueued (SGA_DEBUG_DUMP)
   hipEvent_t ev_fork_cap = nullptr, ev_join_cap = nullptr;   // while `st` is being captured
   bool overlap = true;             // SGA_NO_OVERLAP=1 disables
+  bool side_hybrid = false;        // SGA_HYBRID=1 (experiment): hybrid replay without a CU mask
   bool side_masked = false;        // sB was created with a CU mask (hipExtStreamCreateWithCUMask)
   int branch_only = 0;             // rd_forward_backward: 0 both branches (fork / join), 1 synthesis branch only, 2 hyper branch only
   hipGraphExec_t graph_main = nullptr;   // hybrid replay: the synthesis branch of one iteration (the hyper branch is launched eagerly on the masked stream)
@@ -376,6 +377,8 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     const long long blocks = (long long)a.nphase * a.tiles_per_phase * a.ntiles_n;
     const int per_cu = a.bm == 64 ? 3 : (a.bm == 128 ? 2 : 1);
     a.pair_phases = (a.nphase == 4 && a.ksplit <= 1 && blocks > 256 && blocks <= 256LL * per_cu) ? 1 : 0;
+    static const int xr = getenv("SGA_XCD_REMAP") ? atoi(getenv("SGA_XCD_REMAP")) : 1;
+    a.xcd_remap = (xr && a.ksplit <= 1 && a.ntiles_n == 1 && a.tiles_per_phase % 8 == 0 && blocks >= 256) ? 1 : 0;
   }
   if (defer && a.epi != EPI_BIAS) return SGA_ERR_BAD_ARG;   // the consumer applies "+ bias" only
   if (post) {
@@ -1439,6 +1442,9 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
       if (!masked) (void)hipGetLastError();
     }
     h->side_masked = masked;
+    // Experiment: SGA_HYBRID=1 runs the same hybrid replay with an unmasked side stream of priority SGA_SIDE_PRIORITY
+    // (hardware-queue priorities act on eager streams; graph nodes ignore them)
+    if (const char* hy = getenv("SGA_HYBRID")) h->side_hybrid = hy[0] == '1';
     if ((!masked && hipStreamCreateWithPriority(&h->sB, hipStreamNonBlocking, prio) != hipSuccess) ||
         hipEventCreateWithFlags(&h->ev_fork, evflags) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, evflags) != hipSuccess ||
@@ -1722,7 +1728,7 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
   //   sB: wait(ev_iter: relaxed latents of this iteration exist) . hyper branch . record(ev_side)
   //   st: graph(main chain) . wait(ev_side) . boundary kernel (Adam + next relaxation) . record(ev_iter)
   // Same kernels, same arguments, same order per stream as the two-stream graph: results are bit-identical.
-  if (h->side_masked && h->use_graph && !h->profiling && fb && h->overlap && !h->x3) {
+  if ((h->side_masked || h->side_hybrid) && h->use_graph && !h->profiling && fb && h->overlap && !h->x3) {
     if (!h->graph_main || h->gmain_B != B || h->gmain_H != H || h->gmain_W != W) {
       if (h->graph_main) { (void)hipGraphExecDestroy(h->graph_main); h->graph_main = nullptr; }
       hipGraph_t graph = nullptr;

@@ -94,6 +94,8 @@ struct ConvArgs {
   unsigned long long* stamp;   // measurement only (sga_profile_graph_begin), else null: [0] = min over workgroups of the 100 MHz
                            //   wall clock at entry, [1] = max at exit
   int reduce_batch;        // split-K reduce: issue the slab loads 8 at a time (main chain) or one by one
+  int xcd_remap;           // unsplit launch, tiles_per_phase % 8 == 0: XCD x (blocks b % 8 == x) walks a contiguous eighth of every
+                           //   phase's M tiles, so that the taps' re-gathers of one input region meet in ONE 4 MiB L2
   int pair_phases;         // 4-phase launch whose whole grid is resident at once: walk the phases as 9,6,4,6 taps
   int bm;                  // rows per tile: 128 (default, 4 waves) or 256 (8 waves, big unsplit layers)
   int ksplit;              // max over phases of nsplit[] (1 = no split)
