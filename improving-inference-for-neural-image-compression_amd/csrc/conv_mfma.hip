@@ -73,7 +73,7 @@ constexpr bool glds_instance(int TM, int TN, int WM, int WN, int PRO, bool SMALL
   // 2-wave BN = 96 instance of the hyper branch (same speed alone, but with 56 KB per workgroup it gets in the
   // main chain's way: the iteration measured 1868 against 1827 us)
   return !X3 && !SMALLC && PRO == PRO_NONE &&
-         ((POST == 0 && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2) ||
+         ((POST <= 1 && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2) ||
           (TM == 2 && TN == 4 && WM == 4 && WN == 2));
 }
 
@@ -91,9 +91,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // (nn_models.py:48-59) runs as a post-phase of the SAME launch, on the tile while it is on chip:
 // u = acc + bias goes to LDS, n = gamma . u^2 is a second MFMA contraction out of LDS, s = sqrt(n + beta),
 // v = u * s; (u,) s and v leave in whole 16-byte row pieces.  See the block after the K loop.
-// The tile goes through LDS in parts of post_rows(BN) rows, sized so that a part + two gamma K-chunks fit:
+// The tile goes through LDS in parts of post_rows(BM, BN) rows, sized so that a part + two gamma K-chunks fit:
 // C = 192: 128 x 196 + 2 x 192 x 36 floats = 152 KB;  C = 256 (README.md:58-60, cfg 4): 64 x 260 + 2 x 256 x 36 = 137 KB.
-constexpr int post_rows(int BN) { return BN <= 192 ? 128 : 64; }
+// The 64-row 4-wave instance (two workgroups per CU; layer 1 at cfg 2) holds its whole tile and ONE gamma chunk:
+// 64 x 196 + 192 x 36 floats = 78 KB, the footprint of gdn_tile_kernel, whose launch it replaces.
+constexpr int post_rows(int BM, int BN) { return BM < 128 ? BM : (BN <= 192 ? 128 : 64); }
+constexpr int post_qbufs(int BM) { return BM < 128 ? 1 : 2; }
 template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3, int POST = 0>
 __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = WM * WN * 64;
@@ -107,10 +110,11 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   constexpr bool GLDS = glds_instance(TM, TN, WM, WN, PRO, SMALLC, X3, POST);
   constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (GLDS ? 2 * (BM + BN) * 32 : (BM + BN) * LDK);
   constexpr int EPI_FLOATS = WM * WN * 32 * CPITCH;
-  constexpr int POST_FLOATS = POST ? (post_rows(BN) * (BN + 4) + 2 * BN * LDK) : 0;
+  constexpr int POST_FLOATS = POST ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
   constexpr int LDS_FLOATS0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   constexpr int LDS_FLOATS = LDS_FLOATS0 > POST_FLOATS ? LDS_FLOATS0 : POST_FLOATS;
-  static_assert(!POST || (BM == 256 && (BN == 192 || BN == 256) && NT == 512 && TM == 2 && !X3 && !SMALLC && PRO == PRO_NONE),
+  static_assert(!POST || (((BM == 256 && (BN == 192 || BN == 256) && NT == 512 && TM == 2) ||
+                           (BM == 64 && BN == 192 && NT == 256 && TM == 1 && POST == 1)) && !X3 && !SMALLC && PRO == PRO_NONE),
                 "post-phase instance");
   constexpr int PBX = X3 ? (BN * 12) / NT : 1;     // 16-byte pieces of the 3-plane weight tile per thread
   static_assert(!X3 || (BN * 12) % NT == 0, "x3 loader mismatch");
@@ -534,13 +538,16 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   if constexpr (POST) {
     // ---- fused IGDN (the tile in parts of HR rows; all 8 waves multiply, one barrier per K-step) ----
     constexpr int C = BN, TP = C + 4;
-    constexpr int HR = post_rows(BN), NPART = BM / HR;   // 128 x 2 (C = 192) or 64 x 4 (C = 256)
-    constexpr int PM = HR / 32, PN = 8 / PM;             // post-phase wave grid: PM (rows) x PN (cols) blocks of 32 x (PTN * 32)
+    constexpr int NWV = WM * WN;                         // 8 waves (256-row tiles) or 4 (64-row tile)
+    constexpr int HR = post_rows(BM, BN), NPART = BM / HR;   // 128 x 2 (C = 192), 64 x 4 (C = 256), 64 x 1 (64-row tile)
+    constexpr int PM = HR / 32, PN = NWV / PM;           // post-phase wave grid: PM (rows) x PN (cols) blocks of 32 x (PTN * 32)
     constexpr int PTN = (C / 32) / PN;                   // 3 (32 x 96 per wave) or 2 (32 x 64)
-    constexpr int OW = HR / 64;                          // main-loop wave rows (64 tile rows each) per part
-    static_assert(PM * PN == 8 && PTN * PN * 32 == C && OW * 64 == HR, "post-phase wave grid");
+    constexpr int WR = TM * 32;                          // tile rows of one main-loop wave row
+    constexpr int OW = HR / WR;                          // main-loop wave rows per part
+    constexpr int QBUF = post_qbufs(BM);                 // gamma K-chunk buffers: 2, or 1 where two workgroups share a CU
+    static_assert(PM * PN == NWV && PTN * PN * 32 == C && OW * WR == HR, "post-phase wave grid");
     float* const Tt = smem;                          // [HR][TP]: u of the current part
-    float* const Bq = smem + HR * TP;                // [2][C][LDK]: gamma K-chunks, double-buffered
+    float* const Bq = smem + HR * TP;                // [QBUF][C][LDK]: gamma K-chunks
     const int m4 = wid / PN, n2 = wid % PN;
     float bias_c[TN], beta_c[PTN];                   // per-lane columns: before any store is in flight
 #pragma unroll
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
           for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
-              Tt[((wm % OW) * 64 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * TP + (wn * TN + tn) * 32 + col] =
+              Tt[((wm % OW) * WR + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * TP + (wn * TN + tn) * 32 + col] =
                   acc[tm][tn][reg] + bias_c[tn];
       }
       store_q(0);
@@ -583,9 +590,15 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
         for (int r = 0; r < 16; ++r) acc2[tn][r] = 0.f;
 #pragma unroll
       for (int kc = 0; kc < C / 32; ++kc) {
-        if (kc + 1 < C / 32) store_q((kc + 1) & 1);
-        if (kc + 2 < C / 32) load_q(kc + 2);
-        const float* Bs2 = Bq + (kc & 1) * (C * LDK);
+        if constexpr (QBUF == 2) {
+          if (kc + 1 < C / 32) store_q((kc + 1) & 1);
+          if (kc + 2 < C / 32) load_q(kc + 2);
+        } else if (kc > 0) {                         // one buffer: chunk kc replaces chunk kc - 1 between two barriers
+          store_q(0);
+          if (kc + 1 < C / 32) load_q(kc + 1);
+          lds_barrier();
+        }
+        const float* Bs2 = Bq + (QBUF == 2 ? (kc & 1) : 0) * (C * LDK);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 af = *reinterpret_cast<const f32x4*>(&Tt[(m4 * 32 + col) * TP + kc * 32 + q * 8 + koff]);
@@ -853,7 +866,7 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr bool GLDS = glds_instance(TM, TN, WM, WN, PRO, SMALLC, X3, POST);
   constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (GLDS ? 2 * (BM + BN) * 32 : (BM + BN) * LDK);
   constexpr int EPI_FLOATS = WM * WN * 32 * (TN * 32 + 4);
-  constexpr int POST_FLOATS = POST ? (post_rows(BN) * (BN + 4) + 2 * BN * LDK) : 0;
+  constexpr int POST_FLOATS = POST ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
   constexpr int F0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   const size_t lds = (size_t)(F0 > POST_FLOATS ? F0 : POST_FLOATS) * sizeof(float) + BM * sizeof(long long);
   // once per (instance, device): a process may drive several GPUs, and handles may live on several threads
@@ -948,6 +961,11 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     case 192:
       if (a.bm == 64) {
         if (a.smallc || a.pro != PRO_NONE || a.x3) return (int)hipErrorInvalidValue;
+        if (a.post) {
+          if (a.ksplit > 1 || a.epi != EPI_BIAS || a.Cout != 192 || a.out_coff != 0 || a.out_cs != 192 || a.post_p)
+            return (int)hipErrorInvalidValue;
+          return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 1>(a, stream);
+        }
         return launch_inst<1, 3, 2, 2, PRO_NONE, false>(a, stream);
       }
       if (a.bm == 256) {

@@ -128,6 +128,7 @@ struct sga_handle {
   int dbg_it = -1;                 // iteration being enqueued (SGA_DEBUG_DUMP)
   hipEvent_t ev_fork_cap = nullptr, ev_join_cap = nullptr;   // while `st` is being captured
   bool overlap = true;             // SGA_NO_OVERLAP=1 disables
+  bool fused_post64 = false;       // SGA_FUSED_POST64=1: IGDN post-phase also in the 64-row convolution instance (C = 192)
   bool side_hybrid = false;        // SGA_HYBRID=1 (experiment): hybrid replay without a CU mask
   bool side_masked = false;        // sB was created with a CU mask (hipExtStreamCreateWithCUMask)
   int branch_only = 0;             // rd_forward_backward: 0 both branches (fork / join), 1 synthesis branch only, 2 hyper branch only
@@ -382,12 +383,16 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   }
   if (defer && a.epi != EPI_BIAS) return SGA_ERR_BAD_ARG;   // the consumer applies "+ bias" only
   if (post) {
-    post->fused = h->fused_post && a.bm == 256 && a.ksplit <= 1 && (a.Cout == 192 || a.Cout == 256) && a.Npad == a.Cout &&
+    // 256-row tiles (8 waves, C = 192 / 256); opt-in (SGA_FUSED_POST64=1) also the 64-row 4-wave instance at C = 192:
+    // gs1.fwd + igdn1.fwd 170 -> 156 us alone at cfg 2, but the iteration 1811 -> 1861 us (1816 at the best fork point):
+    // DESIGN_EXPERIMENTS.md A.7
+    const bool post_tile = a.bm == 256 || (a.bm == 64 && a.Cout == 192 && h->fused_post64 && !h->x3);
+    post->fused = h->fused_post && post_tile && a.ksplit <= 1 && (a.Cout == 192 || a.Cout == 256) && a.Npad == a.Cout &&
                   a.epi == EPI_BIAS && a.out_coff == 0 && a.out_cs == a.Cout && post->s_out && post->v_out;
     if (post->fused) {
       a.post = 1; a.post_w = post->gamma_w; a.post_beta = post->beta; a.post_s = post->s_out; a.post_v = post->v_out;
       if (post->drop_u) a.out = nullptr;
-      if (post->w3 && post->p3 && a.Cout == 192) {
+      if (post->w3 && post->p3 && a.Cout == 192 && a.bm == 256) {
         a.post_w3 = post->w3; a.post_p = post->p3;
         post->p3_done = true;
         a.flops += 2.0 * a.B * a.Hout * a.Wout * 75.0 * a.Cout;      // the C -> 3 layer's useful MACs ride in this launch
@@ -1483,6 +1488,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   if (C / 32 != 2 && C / 32 != 4 && C / 32 != 6 && C / 32 != 8) h->fused_gdn = false;
   env = getenv("SGA_KEEP_U");
   h->keep_u = env && env[0] == '1';
+  env = getenv("SGA_FUSED_POST64");
+  h->fused_post64 = env && env[0] == '1';
   env = getenv("SGA_FUSED_POST");
   h->fused_post = !(env && env[0] == '0');
   env = getenv("SGA_PLAN_TILES");

@@ -77,6 +77,28 @@ def test_fused_equals_unfused_bitwise(C, B, H, W):
     fused.close(); legacy.close(); default.close()
 
 
+@pytest.mark.parametrize("C,B,H,W", [(192, 8, 256, 256), (192, 1, 496, 1000)])
+def test_post_phase_in_the_64_row_instance_equals_the_separate_igdn(C, B, H, W, monkeypatch):
+    """nn_models.py:52-55 (layer 1 of g_s at cfg 2: 512 unsplit 64-row tiles): the IGDN as the post-phase of the 4-wave
+    64 x 192 convolution instance (opt-in, SGA_FUSED_POST64=1: faster alone, slower inside the iteration) against the
+    separate tile-kernel launch -- same contraction order, bit for bit."""
+    from sga_amd.codec import SGACodec
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    monkeypatch.setenv("SGA_FUSED_POST64", "1")
+    on = SGACodec(w, C, B, H, W)
+    monkeypatch.setenv("SGA_FUSED_POST64", "0")
+    off = SGACodec(w, C, B, H, W)
+    x = np.random.RandomState(7).rand(B, H, W, 3).astype(np.float32)
+    y, z = off.encode(x)
+    on.profile_begin(); ra = on.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5); names = [k["name"] for k in on.profile_end()]
+    rb = off.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    assert any(n.replace(" ", "").startswith("conv_mfma_kernel<1,3,2,2,0,false,false,1>") for n in names), names
+    assert torch.equal(ra["gy"], rb["gy"]) and torch.equal(ra["gz"], rb["gz"]) and ra["rd_loss"] == rb["rd_loss"]
+    a = on.run(x, 0.01, its=6, seed=1); b = off.run(x, 0.01, its=6, seed=1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    on.close(); off.close()
+
+
 def _codec_env(name, value, *args):
     from sga_amd.codec import SGACodec
     old = os.environ.get(name)
