@@ -123,6 +123,9 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   float* Bs = smem + BM * LDK;
   long long* rowpix = reinterpret_cast<long long*>(smem + LDS_FLOATS);   // [BM] output pixel index or -1
 
+  if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int chunk = tid & 7, lrow = tid >> 3;

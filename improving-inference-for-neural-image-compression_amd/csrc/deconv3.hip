@@ -31,7 +31,7 @@ constexpr int PBW = (B_F4 + 255) / 256;
 // (x - x_tilde)^2 and (255 x - round(255 clip(x_tilde)))^2, and the zero-bordered gradient image
 // gpad = coef * (x_tilde - x) that igdn2.bwd's 3-channel prologue reads.  Same expressions as k_mse.
 struct Deconv3Mse {
-  const float* x; const StepCtx* ctx; ImgSums* sums; float* gpad; int Hp, Wp;
+  const float* x; const StepCtx* ctx; ImgSums* sums; float* gpad; int Hp, Wp; int prio;
 };
 
 template <bool MSE>
@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256) void deconv3_halo_kernel(
     int Wo, int tiles_x, int tiles_y, Deconv3Mse ms) {
   __shared__ __attribute__((aligned(16))) float Hs[NPX * PIT];
   __shared__ __attribute__((aligned(16))) float Bs[NB * PIT];
+  if (ms.prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (ms.prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (ms.prio == 3) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int bid = blockIdx.x;
   const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
@@ -171,6 +174,8 @@ __global__ __launch_bounds__(256) void deconv3_halo_kernel(
 
 }  // namespace
 
+int g_deconv3_prio = 0;      // experiment (SGA_MAIN_WAVE_PRIO), set by sga_create
+
 int launch_deconv3_halo(const float* in, const float* w, const float* bias, float* out, int B,
                         int Hi, int Wi, int C, int Ho, int Wo, hipStream_t stream) {
   const int tiles_x = (Wi + TW - 1) / TW, tiles_y = (Hi + TH - 1) / TH;
@@ -184,6 +189,6 @@ int launch_deconv3_halo_mse(const float* in, const float* w, const float* bias, 
                             ImgSums* sums, float* gpad, int Hp, int Wp, hipStream_t stream) {
   const int tiles_x = (Wi + TW - 1) / TW, tiles_y = (Hi + TH - 1) / TH;
   hipLaunchKernelGGL(deconv3_halo_kernel<true>, dim3(B * tiles_x * tiles_y), dim3(256), 0, stream, in, w,
-                     bias, out, B, Hi, Wi, C, Ho, Wo, tiles_x, tiles_y, Deconv3Mse{x, ctx, sums, gpad, Hp, Wp});
+                     bias, out, B, Hi, Wi, C, Ho, Wo, tiles_x, tiles_y, Deconv3Mse{x, ctx, sums, gpad, Hp, Wp, g_deconv3_prio});
   return (int)hipGetLastError();
 }

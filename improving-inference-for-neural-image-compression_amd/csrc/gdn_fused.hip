@@ -53,6 +53,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
   float* Tt = smem;                              // [BM][TP]
   float* Bs = smem + BM * TP;                    // [C][LDK]
 
+  if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int chunk = tid & 7, lrow = tid >> 3;

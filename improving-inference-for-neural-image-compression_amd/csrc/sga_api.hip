@@ -125,10 +125,20 @@ struct sga_handle {
   bool bm256 = true;               // 256-row 8-wave tile for big unsplit f32 launches (SGA_BM256=0: off)
   bool bm256_split = true;         // ... and, split in two, for single-phase launches of 128 such tiles (SGA_BM256_SPLIT=0: off)
   int fork_at = 0;                 // main-chain launch index at which the hyper branch is forked (SGA_FORK_AT)
+  const char* fork_name = nullptr; // ... or the main-chain launch right before which it is forked (null: fork_at decides)
+  const char* fork2_name = nullptr;// captured graph: the branch's backward half also waits for this main-chain launch (null: no split)
+  hipEvent_t ev_fork2_cap = nullptr;
+  bool fork_auto = true;           // the fork point is chosen per geometry by timing the candidates (off when SGA_FORK_AT is set)
+  bool graph_tuned = false;        // the cached step graph was built with a timed fork point
+  std::vector<hipGraphExec_t> retired_graphs;   // candidate graphs that lost the timing: destroyed with the handle (experiment:
+                                   // destroying them while their sibling is in use crashed the process in the full test suite)
+  int tuned_B = 0, tuned_H = 0, tuned_W = 0;   // geometry the last timed choice (tuned_name) was made for: graphs of that
+  const char* tuned_name = nullptr;            // geometry built without timing (short runs, the stamped graph) reuse it
   int dbg_it = -1;                 // iteration being enqueued (SGA_DEBUG_DUMP)
   hipEvent_t ev_fork_cap = nullptr, ev_join_cap = nullptr;   // while `st` is being captured
   bool overlap = true;             // SGA_NO_OVERLAP=1 disables
-  bool fused_post64 = false;       // SGA_FUSED_POST64=1: IGDN post-phase also in the 64-row convolution instance (C = 192)
+  int main_wave_prio = 0, side_wave_prio = 0;   // experiment: s_setprio of the main chain's / the hyper branch's MFMA kernels
+  bool fused_post64 = true;        // IGDN post-phase also in the 64-row convolution instance (C = 192); SGA_FUSED_POST64=0: off
   bool side_hybrid = false;        // SGA_HYBRID=1 (experiment): hybrid replay without a CU mask
   bool side_masked = false;        // sB was created with a CU mask (hipExtStreamCreateWithCUMask)
   int branch_only = 0;             // rd_forward_backward: 0 both branches (fork / join), 1 synthesis branch only, 2 hyper branch only
@@ -146,7 +156,8 @@ struct sga_handle {
 
   // ---- cached step graph ----
   hipGraphExec_t graph_exec = nullptr;
-  int side_target = 0;             // experiment: split-K target (workgroups per launch) of the hyper branch (SGA_SIDE_TARGET)
+  bool in_hyper = false;           // the launches being enqueued belong to the hyper branch
+  int side_target = 384;           // split-K target (workgroups per launch) of the hyper branch (SGA_SIDE_TARGET; 0: the main chain's 512)
   bool side_last = true;           // graph capture: create the hyper branch's nodes after the main chain's (SGA_SIDE_LAST=0: before)
   int graph_B = 0, graph_H = 0, graph_W = 0, graph_relax = 0;
   hipGraphExec_t bb_graph[2] = {nullptr, nullptr};   // one iteration of bits-back stage 1 / stage 2
@@ -172,6 +183,21 @@ struct sga_handle {
   double gprof_ms = 0.0, gprof_flops = 0.0, gprof_flops_launch = 0.0;
   long long gprof_n = 0;
 };
+
+extern int g_deconv3_prio;
+
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void sga_segv_handler(int sig) {      // debugging aid (SGA_DEBUG_SEGV=1): native frames of a crash inside the library
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "sga: fatal signal, native backtrace:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
 
 namespace {
 
@@ -234,7 +260,8 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   const int tiles = a.tiles_per_phase * a.ntiles_n;
   const int blocks = a.nphase * tiles;
   int target = a.bm == 256 ? 256 : 512;      // ~512 workgroups of (nearly) equal K length (tuned at cfg 2); 256-row: one per CU
-  if (h->cur_part == &h->partB && h->side_target > 0) target = h->side_target;   // hyper branch (second stream)
+  if (h->in_hyper && h->side_target > 0) target = h->side_target;   // hyper branch (whichever stream it runs on: the
+                                                                     // split decides the summation order, i.e. result bits)
   const int bn = a.Npad / a.ntiles_n;
   const bool big = blocks > 256 || (blocks == 256 && a.nphase == 1 && !h->split256);
   // Where the cfg-2 rule does not reach -- grids of more than 256 blocks that still quantise badly into
@@ -364,6 +391,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   }
   a.ksplit = pick_ksplit(h, a);
   a.zeros = h->zeros;
+  a.prio = (h->cur_part == &h->partB) ? h->side_wave_prio : h->main_wave_prio;
 #ifdef SGA_CLOCK_PROBE
   a.clk = (h->clk_mode == 1 && h->profiling && h->profile_by_layer) ? h->clk_probe : nullptr;
   if (h->clk_mode == 2 && h->clk_slots.size() < 40) {
@@ -372,7 +400,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     if (ccs == hipStreamCaptureStatusActive) a.clk = h->clk_probe + h->clk_slots.size() * (size_t)(6 * 16384);
   }
 #endif
-  { static const int rb = getenv("SGA_REDUCE_BATCH") ? atoi(getenv("SGA_REDUCE_BATCH")) : 1;
+  { static const int rb = getenv("SGA_REDUCE_BATCH") ? atoi(getenv("SGA_REDUCE_BATCH")) : 2;
     a.reduce_batch = rb == 2 ? 1 : (rb == 1 ? (h->cur_part == &h->part) : 0); }
   {
     const long long blocks = (long long)a.nphase * a.tiles_per_phase * a.ntiles_n;
@@ -383,9 +411,9 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   }
   if (defer && a.epi != EPI_BIAS) return SGA_ERR_BAD_ARG;   // the consumer applies "+ bias" only
   if (post) {
-    // 256-row tiles (8 waves, C = 192 / 256); opt-in (SGA_FUSED_POST64=1) also the 64-row 4-wave instance at C = 192:
-    // gs1.fwd + igdn1.fwd 170 -> 156 us alone at cfg 2, but the iteration 1811 -> 1861 us (1816 at the best fork point):
-    // DESIGN_EXPERIMENTS.md A.7
+    // 256-row tiles (8 waves, C = 192 / 256) and the 64-row 4-wave instance at C = 192 (gs1.fwd + igdn1.fwd 170 -> 156 us
+    // alone at cfg 2; inside the iteration it pays only with the later fork point of the hyper branch: the joint sweep of
+    // DESIGN_EXPERIMENTS.md A.7; SGA_FUSED_POST64=0 turns it off)
     const bool post_tile = a.bm == 256 || (a.bm == 64 && a.Cout == 192 && h->fused_post64 && !h->x3);
     post->fused = h->fused_post && post_tile && a.ksplit <= 1 && (a.Cout == 192 || a.Cout == 256) && a.Npad == a.Cout &&
                   a.epi == EPI_BIAS && a.out_coff == 0 && a.out_cs == a.Cout && post->s_out && post->v_out;
@@ -552,11 +580,20 @@ int upload_packed(sga_handle* h, PackedConv& pc, const std::vector<float>& host,
 // ------------------------------------------------------------------------------------------
 // weight packing (host).  K is HWIO [kh][kw][ci][co]  (tfc.SignalConv2D)
 // ------------------------------------------------------------------------------------------
+// The hyper branch's N = 288 layers (hs1.fwd, hs2.bwd) as two 192-wide tiles (a quarter of the columns padding, but the
+// 64-row LDS-DMA instance instead of the 2-wave register-staged BN = 96 one).  Round 3: on by default in f32 mode -- alone
+// hs2.bwd 86 -> 62 us; inside the iteration only together with the other "faster alone" variants and a later fork point
+// (joint sweep, DESIGN_EXPERIMENTS.md A.7).  SGA_BN96_AS_192=0 restores the BN = 96 instance.
+bool bn96_as_192(const sga_handle* h) {
+  const char* e = getenv("SGA_BN96_AS_192");
+  return !h->x3 && !(e && e[0] == '0');
+}
+
 // GEMM with N = co, K = ci:  w[t][co][ci] = K[t][ci][co]   (forward of any conv)
 int pack_fwd(sga_handle* h, PackedConv& pc, const float* K, int taps, int ci, int co, int epi) {
   pc.Kc = ci; pc.N = co; pc.nslab = taps;
   pc.bn = conv_pick_bn(co, epi);
-  if (pc.bn == 96 && getenv("SGA_BN96_AS_192") && getenv("SGA_BN96_AS_192")[0] == '1') pc.bn = 192;   // see pack_bwd
+  if (pc.bn == 96 && bn96_as_192(h)) pc.bn = 192;   // see pack_bwd
   pc.Npad = cdiv(co, pc.bn) * pc.bn;
   std::vector<float> w((size_t)taps * pc.Npad * ci, 0.f);
   for (int t = 0; t < taps; ++t)
@@ -572,7 +609,7 @@ int pack_bwd(sga_handle* h, PackedConv& pc, const float* K, int taps, int ci, in
   pc.bn = conv_pick_bn(ci, EPI_BIAS);
   // experiment (SGA_BN96_AS_192=1): N = 288 (1.5 C at C = 192) as two 192-wide tiles (a quarter of them padding) on the
   // 64-row LDS-DMA instance instead of three 96-wide tiles on the 2-wave register-staged one
-  if (pc.bn == 96 && getenv("SGA_BN96_AS_192") && getenv("SGA_BN96_AS_192")[0] == '1') pc.bn = 192;
+  if (pc.bn == 96 && bn96_as_192(h)) pc.bn = 192;
   pc.Npad = cdiv(ci, pc.bn) * pc.bn;
   std::vector<float> w((size_t)taps * pc.Npad * co, 0.f);
   for (int t = 0; t < taps; ++t)
@@ -781,6 +818,7 @@ int gdn_launch(sga_handle* h, GdnArgs& g, hipStream_t st) {
     }
   }
 #endif
+  g.prio = (h->cur_part == &h->partB) ? h->side_wave_prio : h->main_wave_prio;
   HIPCHK(h, launch_gdn_tile(g, st));
   if (h->profiling) {
     HIPCHK(h, hipEventRecord(r.b, st));
@@ -959,9 +997,18 @@ int encode_impl(sga_handle* h, const Geom& g, const float* x, float* y, float* z
 // Hyper-prior branch given z_tilde (and y_tilde for the conditional): p(z_tilde), (mu, sigma) =
 // h_s(z_tilde), p(y_tilde | z_tilde) and, with_grad, the data-gradients back to z_tilde
 // (sga.py:100-108, 126-136 and their part of sga.py:164).  Every launch goes to `st`.
-int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, bool density = false) {
+// `part`: 0 = everything, 1 = the forward half only (up to the conditional's likelihood), 2 = the backward half only
+int hyper_branch_impl(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, bool density, int part);
+int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, bool density = false, int part = 0) {
+  h->in_hyper = true;
+  const int rc = hyper_branch_impl(h, g, with_grad, st, density, part);
+  h->in_hyper = false;
+  return rc;
+}
+int hyper_branch_impl(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, bool density, int part) {
   const int B = g.B, C = h->C;
   const float il = inv_ln2_hw(g);
+  if (part != 2) {
   if (density)   // bits-back: prior DENSITY (bb_sga.py:105-106)
     HIPCHK(h, launch_factorized_pdf(h->zt.p, h->eb_packed, h->ctx, B, g.zh * g.zw, C, il, h->sums,
                                     with_grad ? h->g_zt_eb.p : nullptr, nullptr, nullptr, st));
@@ -976,7 +1023,8 @@ int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, b
   SGACHK(conv3(h, h->hs_f[2], h->hs_bias[2], h->hs1.p, h->C15, B, g.hsh, g.hsw, h->ms.p, true, EPI_BIAS, nullptr, st));
   HIPCHK(h, launch_gaussian(h->yt.p, h->ms.p, h->ctx, B, g.yh, g.yw, g.hsh, g.hsw, C, il, h->scale_bound, h->sums,
                             with_grad ? h->g_yt_rate.p : nullptr, with_grad ? h->g_ms.p : nullptr, st));
-  if (!with_grad) return SGA_OK;
+  }
+  if (!with_grad || part == 1) return SGA_OK;
   h->cur_tag = "hs2.bwd";
   SGACHK(conv3(h, h->hs_b[2], nullptr, h->g_ms.p, 2 * C, B, g.hsh, g.hsw, h->g_hs1.p, false,
                EPI_RELU_MASK, h->hs1.p, st));
@@ -995,11 +1043,16 @@ int hyper_branch(sga_handle* h, const Geom& g, bool with_grad, hipStream_t st, b
 // `side`: called once, right before main-chain launch number `fork_at` (0 = the first one), to
 // enqueue whatever runs concurrently on the second stream.
 int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, hipStream_t st,
-                 int fork_at = 0, const std::function<int()>* side = nullptr) {
+                 int fork_at = 0, const std::function<int()>* side = nullptr, const std::function<int()>* side2 = nullptr) {
   int launches = 0;
-  bool side_started = false;
-  auto tick = [&]() -> int {      // call before every main-chain launch
-    if (side && !side_started && launches >= fork_at) { side_started = true; SGACHK((*side)()); }
+  bool side_started = false, side2_started = false;
+  // call before every main-chain launch.  The hyper branch is forked at launch number `fork_at` (SGA_FORK_AT, experiments)
+  // or, when the handle names one (fork_name: chosen per geometry by sga_run_steps), right before that launch
+  auto tick = [&](const char* name = nullptr) -> int {
+    const bool here = h->fork_name ? (name && strcmp(name, h->fork_name) == 0) : launches >= fork_at;
+    if (side && !side_started && here) { side_started = true; SGACHK((*side)()); }
+    // second fork point (captured graph only): the branch's BACKWARD half may not start before this launch
+    if (side2 && !side2_started && name && h->fork2_name && strcmp(name, h->fork2_name) == 0) { side2_started = true; SGACHK((*side2)()); }
     ++launches;
     return SGA_OK;
   };
@@ -1030,7 +1083,7 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
       pg.w3 = h->gs3_w80; pg.p3 = h->p3.p;
     }
     p3_done = false;
-    SGACHK(tick());
+    SGACHK(tick(kFwd[L]));
     h->cur_tag = kFwd[L];
     SGACHK(deconv_fwd(h, h->gs_f[L], h->gs_bias[L], cur, B, hh, ww, h->u[L].p, EPI_BIAS, st, fz ? &d : nullptr,
                       fz ? &pg : nullptr));
@@ -1043,7 +1096,7 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
     }
     cur = h->v[L].p;
   }
-  SGACHK(tick());
+  SGACHK(tick("gs3.fwd"));
   h->cur_tag = "gs3.fwd";
   bool mse_done = false;     // step: the distortion sums and the gradient image come out of gs3.fwd's epilogue
   SGACHK(deconv_to3(h, h->gs_f[3], h->gs_bias[3], cur, B, hh, ww, g.H, g.W, h->xt.p, st, with_grad ? x : nullptr,
@@ -1067,7 +1120,7 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   }
   Deferred d;
   for (int L = 2; L >= 0; --L) {
-    SGACHK(tick());
+    SGACHK(tick(kIgdnB[L]));
     h->cur_tag = kIgdnB[L];
     if (L == 2 && conv3_fused)
       SGACHK(igdn_bwd(h, h->gs_gdn_b[L], nullptr, h->u[L].p, h->s[L].p, B, hh, ww, h->gB.p, st, nullptr,
@@ -1076,7 +1129,7 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
       SGACHK(igdn_bwd(h, h->gs_gdn_b[L], h->gA.p, h->u[L].p, h->s[L].p, B, hh, ww, h->gB.p, st, &d, nullptr, nullptr, 0, 0,
                       drop_u ? h->v[L].p : nullptr));
     float* dst = (L == 0) ? h->g_yt_dist.p : h->gA.p;
-    SGACHK(tick());
+    SGACHK(tick(kBwd[L]));
     h->cur_tag = kBwd[L];
     d = Deferred();
     SGACHK(conv5s2(h, h->gs_b[L], nullptr, h->gB.p, B, hh, ww, hh / 2, ww / 2, dst, EPI_BIAS, nullptr, st,
@@ -1145,8 +1198,29 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
     h->cur_tag = tag;
     return rc;
   };
-  int rc = synth_branch(h, g, x, with_grad, st, h->fork_at, &side);
-  if (forked && late && rc == SGA_OK) rc = side_body();
+  // Split fork (captured graph, fork2_name set): the branch's forward half is released at the first fork point, its
+  // backward half additionally waits for a second, later main-chain launch.
+  bool forked2 = false;
+  const bool split = late && with_grad && h->fork2_name != nullptr;
+  const std::function<int()> side2 = [&]() -> int {
+    HIPCHK(h, hipEventRecord(h->ev_fork2_cap, st));
+    forked2 = true;
+    return SGA_OK;
+  };
+  int rc = synth_branch(h, g, x, with_grad, st, h->fork_at, &side, split ? &side2 : nullptr);
+  if (forked && late && rc == SGA_OK) {
+    if (split && forked2) {
+      h->cur_part = &h->partB;
+      const char* tag = h->cur_tag;
+      rc = hyper_branch(h, g, with_grad, h->sB, density, 1);
+      if (rc == SGA_OK && hipStreamWaitEvent(h->sB, h->ev_fork2_cap, 0) != hipSuccess) rc = SGA_ERR_HIP;
+      if (rc == SGA_OK) rc = hyper_branch(h, g, with_grad, h->sB, density, 2);
+      h->cur_part = &h->part;
+      h->cur_tag = tag;
+    } else {
+      rc = side_body();
+    }
+  }
   // always join, even on error, so a capture in progress is not left forked
   if (forked) {
     const hipError_t e1 = hipEventRecord(evj, h->sB);
@@ -1193,9 +1267,11 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
 
 void free_all(sga_handle* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  for (hipGraphExec_t gx : h->retired_graphs) (void)hipGraphExecDestroy(gx);
   if (h->graph_main) (void)hipGraphExecDestroy(h->graph_main);
   for (int k = 0; k < 2; ++k) if (h->bb_graph[k]) (void)hipGraphExecDestroy(h->bb_graph[k]);
   for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  if (h->ev_fork2_cap) (void)hipEventDestroy(h->ev_fork2_cap);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_fork_cap) (void)hipEventDestroy(h->ev_fork_cap);
@@ -1220,6 +1296,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   if (!(cfg->scale_bound >= 0.f) || !(cfg->scale_bound < 1e30f)) return SGA_ERR_BAD_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return SGA_ERR_NO_DEVICE;
+  if (getenv("SGA_DEBUG_SEGV")) { signal(SIGSEGV, sga_segv_handler); signal(SIGBUS, sga_segv_handler); }
   sga_handle* h = new (std::nothrow) sga_handle();
   if (!h) return SGA_ERR_NOMEM;
   h->cfg = *cfg;
@@ -1227,6 +1304,11 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   const int C = cfg->num_filters;
   h->C = C; h->C15 = (int)(C * 1.5); h->C2 = 2 * C;
   h->haN = cfg->bits_back ? 2 * C : C;
+  {
+    const char* pe = getenv("SGA_PRECISION");
+    h->x3 = cfg->precision == SGA_PRECISION_BF16X3 ||
+            (cfg->precision == SGA_PRECISION_DEFAULT && pe && strcmp(pe, "bf16x3") == 0);
+  }
   int st = SGA_OK;
   auto fail = [&](int code) { free_all(h); delete h; return code; };
 #define TRY(expr) do { st = (expr); if (st != SGA_OK) return fail(st); } while (0)
@@ -1282,8 +1364,10 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
       // Measured at cfg 2: GEMM 40.7 us + col2im 22.4 us = 63 us alone against 75.6 us for the halo
       // kernel, but inside the iteration the pair is 3 us SLOWER (two launches, 64 KB of LDS per 8-wave workgroup next
       // to the hyper branch): the halo kernel stays the default, SGA_GS3_GEMM=1 selects this path.
+      // Round 3: ON by default -- together with the other faster-alone variants and the later fork point of the hyper branch
+      // the iteration is 30 us shorter (joint sweep, DESIGN_EXPERIMENTS.md A.7); SGA_GS3_GEMM=0 selects the halo kernel.
       const char* eg = getenv("SGA_GS3_GEMM");
-      h->gs3_gemm = eg && eg[0] == '1';
+      h->gs3_gemm = !(eg && eg[0] == '0');
       eg = getenv("SGA_POST_P");
       h->post_p = eg && eg[0] == '1';
     }
@@ -1454,7 +1538,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
         hipEventCreateWithFlags(&h->ev_fork, evflags) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, evflags) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork_cap, evflags) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join_cap, evflags) != hipSuccess)
+        hipEventCreateWithFlags(&h->ev_join_cap, evflags) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork2_cap, evflags) != hipSuccess)
       return fail(SGA_ERR_HIP);
   }
   env = getenv("SGA_PRECISION");
@@ -1476,7 +1561,11 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   env = getenv("SGA_BM64_MAX");
   if (env) h->bm64_max = atoi(env);
   env = getenv("SGA_FORK_AT");
-  if (env) h->fork_at = atoi(env);
+  if (env) { h->fork_at = atoi(env); h->fork_auto = false; }
+  env = getenv("SGA_FORK_NAME");       // experiments: pin the named fork point(s) ("start" = at the first launch)
+  if (env) { h->fork_auto = false; h->fork_name = strcmp(env, "start") == 0 ? nullptr : strdup(env); }
+  env = getenv("SGA_FORK2_NAME");
+  if (env) { h->fork_auto = false; h->fork2_name = strcmp(env, "none") == 0 ? nullptr : strdup(env); }
   env = getenv("SGA_SIDE_LAST");
   if (env) h->side_last = env[0] == '1';
   env = getenv("SGA_SIDE_TARGET");
@@ -1488,8 +1577,12 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   if (C / 32 != 2 && C / 32 != 4 && C / 32 != 6 && C / 32 != 8) h->fused_gdn = false;
   env = getenv("SGA_KEEP_U");
   h->keep_u = env && env[0] == '1';
+  env = getenv("SGA_MAIN_WAVE_PRIO");
+  if (env) { h->main_wave_prio = atoi(env); g_deconv3_prio = h->main_wave_prio; }
+  env = getenv("SGA_SIDE_WAVE_PRIO");
+  if (env) h->side_wave_prio = atoi(env);
   env = getenv("SGA_FUSED_POST64");
-  h->fused_post64 = env && env[0] == '1';
+  h->fused_post64 = !(env && env[0] == '0');
   env = getenv("SGA_FUSED_POST");
   h->fused_post = !(env && env[0] == '0');
   env = getenv("SGA_PLAN_TILES");
@@ -1778,27 +1871,97 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
   }
 
   bool graphed = false;
+  int tuned_done = 0;              // iterations of this call already run by the fork-point candidates
   if (h->use_graph && !h->profiling) {
-    if (!h->graph_exec || h->graph_B != B || h->graph_H != H || h->graph_W != W ||
-        h->graph_relax != h->relax) {
-      if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    auto capture = [&]() -> hipGraphExec_t {
+      hipGraphExec_t ex = nullptr;
       hipGraph_t graph = nullptr;
       if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         const int rc = enqueue_step(st);
         const hipError_t ec = hipStreamEndCapture(st, &graph);
-        if (rc == SGA_OK && ec == hipSuccess && graph &&
-            hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-          h->graph_B = B; h->graph_H = H; h->graph_W = W; h->graph_relax = h->relax;
-        } else {
-          h->graph_exec = nullptr;
-        }
+        if (!(rc == SGA_OK && ec == hipSuccess && graph && hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0) == hipSuccess))
+          ex = nullptr;
         if (graph) (void)hipGraphDestroy(graph);
       }
       (void)hipGetLastError();
+      return ex;
+    };
+    // Where the hyper branch is forked does not change a single bit of the result (same kernels, same arguments, other
+    // graph edges), but it decides which main-chain launches its kernels fall on: +-50 us per iteration at cfg 2, and the
+    // best point differs between geometries (cfg 2, B = 8: before gs3.fwd 1780 us, at the start 1840 us; one Kodak image:
+    // 1.59 against 1.52 ms).  So a call with enough iterations left times the three candidates once per geometry -- on
+    // the run's own iterations: 8 replays of each candidate graph, which count -- and keeps the fastest graph
+    // (DESIGN.md 3.7).  SGA_FORK_AT=<n> pins the point instead.
+    constexpr int kTuneReps = 8;
+    const bool tune = h->fork_auto && fb && h->overlap && !h->x3 && !h->gprof && n >= 100;
+    const bool stale = !h->graph_exec || h->graph_B != B || h->graph_H != H || h->graph_W != W || h->graph_relax != h->relax;
+    if (stale || (tune && !h->graph_tuned)) {
+      if (h->graph_exec) {
+        // replays of the old graph may still be queued (a short run followed at once by a long one): let them finish
+        // before the executable graph is destroyed
+        HIPCHK(h, hipStreamSynchronize(st));
+        (void)hipGraphExecDestroy(h->graph_exec);
+        h->graph_exec = nullptr;
+      }
+      h->graph_tuned = false;
+      if (!tune) {
+        if (h->fork_auto) h->fork_name = (h->tuned_B == B && h->tuned_H == H && h->tuned_W == W) ? h->tuned_name : nullptr;
+        h->graph_exec = capture();
+        h->graph_tuned = h->fork_auto && h->tuned_B == B && h->tuned_H == H && h->tuned_W == W;
+      } else {
+        static const char* const cands[3] = {nullptr, "gs2.fwd", "gs3.fwd"};
+        static const bool verbose = getenv("SGA_FORK_VERBOSE") != nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        HIPCHK(h, hipEventCreate(&e0));
+        HIPCHK(h, hipEventCreate(&e1));
+        float best_ms = 0.f;
+        hipGraphExec_t best = nullptr;
+        const char* best_name = nullptr;
+        for (int c = 0; c < 3; ++c) {
+          h->fork_name = cands[c];
+          hipGraphExec_t ex = capture();
+          if (!ex) continue;
+          float ms = 0.f;
+          bool ok = true;                                            // replays to settle (the first candidate also absorbs
+          const int settle = c == 0 ? 3 : 1;                         // the clock ramp of a fresh run), kTuneReps timed: all
+          for (int r = 0; r < settle && ok; ++r) ok = hipGraphLaunch(ex, st) == hipSuccess;   // of them are iterations of this run
+          ok = ok && hipEventRecord(e0, st) == hipSuccess;
+          for (int r = 0; r < kTuneReps && ok; ++r) ok = hipGraphLaunch(ex, st) == hipSuccess;
+          ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+               hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+          if (!ok) {      // a failed launch leaves the run in an unknown state: report it
+            h->retired_graphs.push_back(ex);
+            if (best) h->retired_graphs.push_back(best);
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            h->fork_name = nullptr;
+            HIPCHK(h, hipErrorUnknown);
+          }
+          tuned_done += settle + kTuneReps;
+          if (verbose)
+            fprintf(stderr, "sga fork point %-8s B=%d %dx%d: %.1f us per iteration\n", cands[c] ? cands[c] : "start", B, H, W,
+                    ms * 1000.f / kTuneReps);
+          // the losing candidates are kept until the handle goes (two small executable graphs per tuned geometry): see
+          // sga_handle::retired_graphs
+          if (!best || ms < best_ms) {
+            if (best) h->retired_graphs.push_back(best);
+            best = ex; best_ms = ms; best_name = cands[c];
+          } else {
+            h->retired_graphs.push_back(ex);
+          }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        h->graph_exec = best;
+        h->fork_name = best_name;
+        h->graph_tuned = best != nullptr;
+        if (best) { h->tuned_B = B; h->tuned_H = H; h->tuned_W = W; h->tuned_name = best_name; }
+        if (!h->graph_exec) { h->fork_name = nullptr; h->graph_exec = capture(); }
+      }
+      if (h->graph_exec) { h->graph_B = B; h->graph_H = H; h->graph_W = W; h->graph_relax = h->relax; }
     }
     graphed = h->graph_exec != nullptr;
   }
-  for (int k = 0; k < n; ++k) {
+  for (int k = tuned_done; k < n; ++k) {
     h->dbg_it = h->run_it + k;
     if (graphed) HIPCHK(h, hipGraphLaunch(h->graph_exec, st));
     else SGACHK(enqueue_step(st));

@@ -94,6 +94,7 @@ struct ConvArgs {
   unsigned long long* stamp;   // measurement only (sga_profile_graph_begin), else null: [0] = min over workgroups of the 100 MHz
                            //   wall clock at entry, [1] = max at exit
   int reduce_batch;        // split-K reduce: issue the slab loads 8 at a time (main chain) or one by one
+  int prio;                // wave priority (s_setprio) for the whole launch: experiment, SGA_MAIN_WAVE_PRIO / SGA_SIDE_WAVE_PRIO
   int xcd_remap;           // unsplit launch, tiles_per_phase % 8 == 0: XCD x (blocks b % 8 == x) walks a contiguous eighth of every
                            //   phase's M tiles, so that the taps' re-gathers of one input region meet in ONE 4 MiB L2
   int pair_phases;         // 4-phase launch whose whole grid is resident at once: walk the phases as 9,6,4,6 taps
@@ -140,6 +141,7 @@ struct GdnArgs {
   float* s_out_p;          // forward IGDN: sqrt(n) (or null)
   float* u_out;            // forward: T written back (needed when T was assembled here), or null
   double flops;            // algorithmic flops (profiling only)
+  int prio;                // wave priority (experiment)
 #ifdef SGA_CLOCK_PROBE
   unsigned long long* clk; // measurement build: per workgroup 8 x u64 = wall clock (100 MHz) at entry, after the prologue,
                            //   after the fill, after the contraction, at exit, hw_id | xcc_id << 32
