@@ -80,7 +80,7 @@ def test_fused_equals_unfused_bitwise(C, B, H, W):
 @pytest.mark.parametrize("C,B,H,W", [(192, 8, 256, 256), (192, 1, 496, 1000)])
 def test_post_phase_in_the_64_row_instance_equals_the_separate_igdn(C, B, H, W, monkeypatch):
     """nn_models.py:52-55 (layer 1 of g_s at cfg 2: 512 unsplit 64-row tiles): the IGDN as the post-phase of the 4-wave
-    64 x 192 convolution instance (opt-in, SGA_FUSED_POST64=1: faster alone, slower inside the iteration) against the
+    64 x 192 convolution instance (default since the joint schedule sweep; SGA_FUSED_POST64=0 turns it off) against the
     separate tile-kernel launch -- same contraction order, bit for bit."""
     from sga_amd.codec import SGACodec
     w = sga_amd.make_synthetic_weights(C, seed=0)
@@ -166,7 +166,7 @@ def test_step_boundary_kernel_equals_the_three_launches(C, B, H, W):
 @pytest.mark.parametrize("C,B,H,W", [(64, 2, 64, 64), (64, 1, 50, 70), (192, 2, 256, 256), (256, 1, 96, 80)])
 def test_gs3_as_gemm_plus_col2im_equals_the_halo_kernel(C, B, H, W):
     """The C -> 3 transposed convolution (nn_models.py:60-63) as a plain GEMM over all 25 x 3 kernel columns + a col2im
-    kernel with the distortion in it (deconv3_gemm.hip, SGA_GS3_GEMM=1; opt-in: faster alone, not inside the iteration)
+    kernel with the distortion in it (deconv3_gemm.hip; the default since the joint schedule sweep, SGA_GS3_GEMM=0: halo kernel)
     against the default halo-tiled kernel: the same products summed in another order -- reconstruction, gradients and
     the distortion sums agree to float32 rounding, and ragged sizes crop identically."""
     w = sga_amd.make_synthetic_weights(C, seed=0)
