@@ -73,7 +73,7 @@ constexpr bool glds_instance(int TM, int TN, int WM, int WN, int PRO, bool SMALL
   // 2-wave BN = 96 instance of the hyper branch (same speed alone, but with 56 KB per workgroup it gets in the
   // main chain's way: the iteration measured 1868 against 1827 us)
   return !X3 && !SMALLC && PRO == PRO_NONE &&
-         ((POST <= 1 && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2) ||
+         (((POST <= 1 || POST == 3) && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2) ||
           (TM == 2 && TN == 4 && WM == 4 && WN == 2));
 }
 
@@ -108,13 +108,18 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
 
   constexpr int CPITCH = TN * 32 + 4;         // epilogue staging pitch (floats) per wave row
   constexpr bool GLDS = glds_instance(TM, TN, WM, WN, PRO, SMALLC, X3, POST);
-  constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (GLDS ? 2 * (BM + BN) * 32 : (BM + BN) * LDK);
-  constexpr int EPI_FLOATS = WM * WN * 32 * CPITCH;
-  constexpr int POST_FLOATS = POST ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
+  // POST = 3 is not a post-phase but the LOW-FOOTPRINT form of the 64-row instance (hyper branch, opt-in): ONE LDS stage and the
+  // epilogue staged two waves at a time -> 33 KB instead of 64.5 KB, so that a workgroup fits beside a 117-KB workgroup of the
+  // 256-row instance (gs2.bwd holds every CU from start to end; the branch's backward half otherwise waits for it)
+  constexpr bool LOWF = POST == 3;
+  constexpr bool HASPOST = POST == 1 || POST == 2;
+  constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (GLDS ? (LOWF ? 1 : 2) * (BM + BN) * 32 : (BM + BN) * LDK);
+  constexpr int EPI_FLOATS = (LOWF ? 2 : WM * WN) * 32 * CPITCH;
+  constexpr int POST_FLOATS = HASPOST ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
   constexpr int LDS_FLOATS0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   constexpr int LDS_FLOATS = LDS_FLOATS0 > POST_FLOATS ? LDS_FLOATS0 : POST_FLOATS;
-  static_assert(!POST || (((BM == 256 && (BN == 192 || BN == 256) && NT == 512 && TM == 2) ||
-                           (BM == 64 && BN == 192 && NT == 256 && TM == 1 && POST == 1)) && !X3 && !SMALLC && PRO == PRO_NONE),
+  static_assert(!POST || (((BM == 256 && (BN == 192 || BN == 256) && NT == 512 && TM == 2 && HASPOST) ||
+                           (BM == 64 && BN == 192 && NT == 256 && TM == 1 && (POST == 1 || POST == 3))) && !X3 && !SMALLC && PRO == PRO_NONE),
                 "post-phase instance");
   constexpr int PBX = X3 ? (BN * 12) / NT : 1;     // 16-byte pieces of the 3-plane weight tile per thread
   static_assert(!X3 || (BN * 12) % NT == 0, "x3 loader mismatch");
@@ -391,6 +396,41 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
       issue(0, ci0);
     }
     __syncthreads();
+    if constexpr (LOWF) {
+      // one stage: load, barrier, multiply, barrier.  Nothing overlaps inside this workgroup; it runs beside a big one.
+      const int ra1 = (wm * TM) * 32 + (lane & 31), rb1 = BM + (wn * TN) * 32 + (lane & 31), hl1 = lane >> 5;
+      for (int ks = k_begin; ks < k_end; ++ks) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = 2 * q + hl1;
+          f32x4 af[TM], bf[TN];
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) {
+            const int r = ra1 + tm * 32;
+            af[tm] = *reinterpret_cast<const f32x4*>(&smem[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
+          }
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const int r = rb1 + tn * 32;
+            bf[tn] = *reinterpret_cast<const f32x4*>(&smem[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+              for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][r], bf[tn][r], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();                                   // every wave is done with the stage
+        if (ks + 1 < k_end) {
+          ci0 += BK;
+          if (ci0 >= a.Cin) { ci0 = 0; ++tapi; tap_setup(tapi); }
+          issue(0, ci0);
+        }
+        __syncthreads();                                   // (waits for the DMA: vmcnt(0) before the barrier)
+      }
+    } else {
     const int ra_ = (wm * TM) * 32 + (lane & 31);
     const int rb_ = BM + (wn * TN) * 32 + (lane & 31);
     const int hlf = lane >> 5;
@@ -425,6 +465,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
               acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][r], bf[tn][r], acc[tm][tn], 0, 0, 0);
       }
       __syncthreads();
+    }
     }
   } else
   for (int ks = k_begin; ks < k_end; ++ks) {
@@ -538,7 +579,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   // ---- epilogue -------------------------------------------------------------------------------
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
   const int half = lane >> 5, col = lane & 31;
-  if constexpr (POST) {
+  if constexpr (HASPOST) {
     // ---- fused IGDN (the tile in parts of HR rows; all 8 waves multiply, one barrier per K-step) ----
     constexpr int C = BN, TP = C + 4;
     constexpr int NWV = WM * WN;                         // 8 waves (256-row tiles) or 4 (64-row tile)
@@ -748,9 +789,13 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   // output rows (coalesced float4 stores and aux loads instead of 4-byte column scatters).
   const int epi = a.ksplit > 1 ? -1 : a.epi;      // split-K: raw partial sums, epilogue in the reduce
   float* const outp = a.ksplit > 1 ? a.part + (size_t)split * a.slab : a.out;
-  float* Cs = smem + wid * (32 * CPITCH);
+  float* Cs = smem + (LOWF ? (wid & 1) : wid) * (32 * CPITCH);
   constexpr int F4_PER_ROW = TN * 8;
   constexpr int F4_ITERS = (32 * F4_PER_ROW) / 64;
+  constexpr int EPI_ROUNDS = LOWF ? WM * WN / 2 : 1;      // low-footprint form: two waves stage at a time
+#pragma unroll
+  for (int round = 0; round < EPI_ROUNDS; ++round) {
+  if (!LOWF || (wid >> 1) == round) {
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -806,6 +851,9 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
       *reinterpret_cast<f32x4*>(outp + o) = v;
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  }
+  if constexpr (LOWF) __syncthreads();
   }
   SGA_PROBE_END();
 }
@@ -867,9 +915,10 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr bool GLDS = glds_instance(TM, TN, WM, WN, PRO, SMALLC, X3, POST);
-  constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (GLDS ? 2 * (BM + BN) * 32 : (BM + BN) * LDK);
-  constexpr int EPI_FLOATS = WM * WN * 32 * (TN * 32 + 4);
-  constexpr int POST_FLOATS = POST ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
+  constexpr bool LOWF = POST == 3;
+  constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (GLDS ? (LOWF ? 1 : 2) * (BM + BN) * 32 : (BM + BN) * LDK);
+  constexpr int EPI_FLOATS = (LOWF ? 2 : WM * WN) * 32 * (TN * 32 + 4);
+  constexpr int POST_FLOATS = (POST == 1 || POST == 2) ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
   constexpr int F0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   const size_t lds = (size_t)(F0 > POST_FLOATS ? F0 : POST_FLOATS) * sizeof(float) + BM * sizeof(long long);
   // once per (instance, device): a process may drive several GPUs, and handles may live on several threads
@@ -939,7 +988,7 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
   if (a.bm == 64) tm = 1;
   snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%s,%d>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
            a.smallc ? "true" : "false", (a.x3 && !a.smallc && bn != 32) ? "true" : "false",
-           a.post ? (a.post_p ? 2 : 1) : 0);
+           a.post ? (a.post_p ? 2 : 1) : (a.lowfoot && a.bm == 64 && bn == 192 ? 3 : 0));
 }
 
 int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream) {
@@ -969,6 +1018,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
             return (int)hipErrorInvalidValue;
           return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 1>(a, stream);
         }
+        if (a.lowfoot) return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 3>(a, stream);
         return launch_inst<1, 3, 2, 2, PRO_NONE, false>(a, stream);
       }
       if (a.bm == 256) {

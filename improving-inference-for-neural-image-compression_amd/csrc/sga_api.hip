@@ -156,6 +156,7 @@ struct sga_handle {
 
   // ---- cached step graph ----
   hipGraphExec_t graph_exec = nullptr;
+  bool side_lowfoot = false;       // SGA_SIDE_LOWFOOT=1: the hyper branch's 64-row launches in the 33-KB form (fit beside gs2.bwd)
   bool in_hyper = false;           // the launches being enqueued belong to the hyper branch
   int side_target = 384;           // split-K target (workgroups per launch) of the hyper branch (SGA_SIDE_TARGET; 0: the main chain's 512)
   bool side_last = true;           // graph capture: create the hyper branch's nodes after the main chain's (SGA_SIDE_LAST=0: before)
@@ -392,6 +393,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   a.ksplit = pick_ksplit(h, a);
   a.zeros = h->zeros;
   a.prio = (h->cur_part == &h->partB) ? h->side_wave_prio : h->main_wave_prio;
+  a.lowfoot = (h->in_hyper && h->side_lowfoot && a.bm == 64 && !a.post && !a.smallc && a.pro == PRO_NONE && !h->x3) ? 1 : 0;
 #ifdef SGA_CLOCK_PROBE
   a.clk = (h->clk_mode == 1 && h->profiling && h->profile_by_layer) ? h->clk_probe : nullptr;
   if (h->clk_mode == 2 && h->clk_slots.size() < 40) {
@@ -1577,6 +1579,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   if (C / 32 != 2 && C / 32 != 4 && C / 32 != 6 && C / 32 != 8) h->fused_gdn = false;
   env = getenv("SGA_KEEP_U");
   h->keep_u = env && env[0] == '1';
+  env = getenv("SGA_SIDE_LOWFOOT");
+  h->side_lowfoot = env && env[0] == '1';
   env = getenv("SGA_MAIN_WAVE_PRIO");
   if (env) { h->main_wave_prio = atoi(env); g_deconv3_prio = h->main_wave_prio; }
   env = getenv("SGA_SIDE_WAVE_PRIO");

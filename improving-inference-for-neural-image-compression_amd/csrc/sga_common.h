@@ -94,6 +94,7 @@ struct ConvArgs {
   unsigned long long* stamp;   // measurement only (sga_profile_graph_begin), else null: [0] = min over workgroups of the 100 MHz
                            //   wall clock at entry, [1] = max at exit
   int reduce_batch;        // split-K reduce: issue the slab loads 8 at a time (main chain) or one by one
+  int lowfoot;             // 64-row instance in its low-footprint form (one LDS stage, 33 KB): hyper branch, SGA_SIDE_LOWFOOT=1
   int prio;                // wave priority (s_setprio) for the whole launch: experiment, SGA_MAIN_WAVE_PRIO / SGA_SIDE_WAVE_PRIO
   int xcd_remap;           // unsplit launch, tiles_per_phase % 8 == 0: XCD x (blocks b % 8 == x) walks a contiguous eighth of every
                            //   phase's M tiles, so that the taps' re-gathers of one input region meet in ONE 4 MiB L2
