@@ -260,7 +260,8 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   if (a.out_coff != 0 || a.out_cs != a.Cout || (a.Cout & 3)) return 1;
   const int tiles = a.tiles_per_phase * a.ntiles_n;
   const int blocks = a.nphase * tiles;
-  int target = a.bm == 256 ? 256 : 512;      // ~512 workgroups of (nearly) equal K length (tuned at cfg 2); 256-row: one per CU
+  static const int main_target = getenv("SGA_MAIN_TARGET") ? atoi(getenv("SGA_MAIN_TARGET")) : 512;   // experiments
+  int target = a.bm == 256 ? 256 : main_target;      // ~512 workgroups of (nearly) equal K length (tuned at cfg 2); 256-row: one per CU
   if (h->in_hyper && h->side_target > 0) target = h->side_target;   // hyper branch (whichever stream it runs on: the
                                                                      // split decides the summation order, i.e. result bits)
   const int bn = a.Npad / a.ntiles_n;

@@ -220,3 +220,33 @@ def test_post_phase_products_equal_the_standalone_gemm(C, B, H, W):
     (ma, xa), (mb, xb) = ships.evaluate(x, a[0], a[1], want_x_hat=True), ref.evaluate(x, a[0], a[1], want_x_hat=True)
     assert torch.equal(xa, xb)
     ships.close(); ref.close()
+
+
+def test_results_do_not_depend_on_the_schedule(monkeypatch):
+    """where the hyper branch is forked (timed per geometry in runs of >= 100 iterations), whether it is forked
+    at all, and whether the step graph is replayed or launched eagerly are schedule choices -- the same kernels with the same
+    arguments -- so the latents and metrics of a run must agree BIT FOR BIT across them.  (Regression: the branch's split-K
+    target used to be a property of the stream it ran on, so unforked execution summed in another order.)"""
+    from sga_amd.codec import SGACodec
+    C, B, H, W = 192, 2, 128, 128
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    x = np.random.RandomState(3).rand(B, H, W, 3).astype(np.float32)
+
+    def run(env):
+        for k in ("SGA_FORK_AT", "SGA_FORK_NAME", "SGA_FORK2_NAME", "SGA_NO_OVERLAP", "SGA_NO_GRAPH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = SGACodec(w, C, B, H, W)
+        out = c.run(x, 0.01, its=130, seed=4)            # >= 100 iterations: the timed fork point when nothing pins it
+        g = c.step_grads(x, out[0], out[1], 0.3, 0.01, seed=2, it=7)
+        c.close()
+        return out, g
+
+    ref, gref = run({})
+    for env in ({"SGA_FORK_AT": "0"}, {"SGA_FORK_NAME": "gs2.fwd"}, {"SGA_FORK_NAME": "gs3.fwd"},
+                {"SGA_FORK_NAME": "gs2.fwd", "SGA_FORK2_NAME": "gs2.bwd"}, {"SGA_NO_OVERLAP": "1"}, {"SGA_NO_GRAPH": "1"}):
+        out, g = run(env)
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), env
+        assert torch.equal(out[2][:, [0, 1, 4, 5, 6]], ref[2][:, [0, 1, 4, 5, 6]]), env
+        assert torch.equal(g["gy"], gref["gy"]) and torch.equal(g["gz"], gref["gz"]) and g["rd_loss"] == gref["rd_loss"], env
