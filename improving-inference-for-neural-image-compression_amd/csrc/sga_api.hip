@@ -1905,8 +1905,8 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
         // replays of the old graph may still be queued (a short run followed at once by a long one): let them finish
         // before the executable graph is destroyed
         HIPCHK(h, hipStreamSynchronize(st));
-        (void)hipGraphExecDestroy(h->graph_exec);
-        h->graph_exec = nullptr;
+        h->retired_graphs.push_back(h->graph_exec);      // retired, not destroyed (see retired_graphs): an executable graph of
+        h->graph_exec = nullptr;                         // ~30 kernel nodes per geometry change, freed with the handle
       }
       h->graph_tuned = false;
       if (!tune) {
