@@ -130,6 +130,7 @@ struct sga_handle {
   hipEvent_t ev_fork2_cap = nullptr;
   bool fork_auto = true;           // the fork point is chosen per geometry by timing the candidates (off when SGA_FORK_AT is set)
   bool graph_tuned = false;        // the cached step graph was built with a timed fork point
+  bool bb_graph_tuned = false;     // ... and the bits-back stage-1 graph
   std::vector<hipGraphExec_t> retired_graphs;   // candidate graphs that lost the timing: destroyed with the handle (experiment:
                                    // destroying them while their sibling is in use crashed the process in the full test suite)
   int tuned_B = 0, tuned_H = 0, tuned_W = 0;   // geometry the last timed choice (tuned_name) was made for: graphs of that
@@ -1268,6 +1269,60 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
   return SGA_OK;
 }
 
+// The fork point of the hyper branch, chosen by time: captures one step graph per candidate (`capture` records
+// one iteration under the current h->fork_name), replays each a few times -- on the caller's live state: the replays are
+// iterations of the run and are counted in *done -- and returns the fastest; the others are retired (sga_handle::retired_graphs).
+template <typename Cap>
+int timed_fork_choice(sga_handle* h, hipStream_t st, int B, int H, int W, Cap&& capture, hipGraphExec_t* out, int* done) {
+  constexpr int kTuneReps = 8;
+  static const char* const cands[3] = {nullptr, "gs2.fwd", "gs3.fwd"};
+  static const bool verbose = getenv("SGA_FORK_VERBOSE") != nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIPCHK(h, hipEventCreate(&e0));
+  HIPCHK(h, hipEventCreate(&e1));
+  float best_ms = 0.f;
+  hipGraphExec_t best = nullptr;
+  const char* best_name = nullptr;
+  for (int c = 0; c < 3; ++c) {
+    h->fork_name = cands[c];
+    hipGraphExec_t ex = capture();
+    if (!ex) continue;
+    float ms = 0.f;
+    bool ok = true;                                            // replays to settle (the first candidate also absorbs
+    const int settle = c == 0 ? 3 : 1;                         // the clock ramp of a fresh run), kTuneReps timed
+    for (int r = 0; r < settle && ok; ++r) ok = hipGraphLaunch(ex, st) == hipSuccess;
+    ok = ok && hipEventRecord(e0, st) == hipSuccess;
+    for (int r = 0; r < kTuneReps && ok; ++r) ok = hipGraphLaunch(ex, st) == hipSuccess;
+    ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+         hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+    if (!ok) {      // a failed launch leaves the run in an unknown state: report it
+      h->retired_graphs.push_back(ex);
+      if (best) h->retired_graphs.push_back(best);
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      h->fork_name = nullptr;
+      HIPCHK(h, hipErrorUnknown);
+    }
+    *done += settle + kTuneReps;
+    if (verbose)
+      fprintf(stderr, "sga fork point %-8s B=%d %dx%d: %.1f us per iteration\n", cands[c] ? cands[c] : "start", B, H, W,
+              ms * 1000.f / kTuneReps);
+    // the losing candidates are kept until the handle goes (two small executable graphs per tuned geometry): see
+    // sga_handle::retired_graphs
+    if (!best || ms < best_ms) {
+      if (best) h->retired_graphs.push_back(best);
+      best = ex; best_ms = ms; best_name = cands[c];
+    } else {
+      h->retired_graphs.push_back(ex);
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *out = best;
+  h->fork_name = best_name;
+  if (best) { h->tuned_B = B; h->tuned_H = H; h->tuned_W = W; h->tuned_name = best_name; }
+  return SGA_OK;
+}
+
 void free_all(sga_handle* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   for (hipGraphExec_t gx : h->retired_graphs) (void)hipGraphExecDestroy(gx);
@@ -1897,7 +1952,6 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
     // 1.59 against 1.52 ms).  So a call with enough iterations left times the three candidates once per geometry -- on
     // the run's own iterations: 8 replays of each candidate graph, which count -- and keeps the fastest graph
     // (DESIGN.md 3.7).  SGA_FORK_AT=<n> pins the point instead.
-    constexpr int kTuneReps = 8;
     const bool tune = h->fork_auto && fb && h->overlap && !h->x3 && !h->gprof && n >= 100;
     const bool stale = !h->graph_exec || h->graph_B != B || h->graph_H != H || h->graph_W != W || h->graph_relax != h->relax;
     if (stale || (tune && !h->graph_tuned)) {
@@ -1914,52 +1968,8 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
         h->graph_exec = capture();
         h->graph_tuned = h->fork_auto && h->tuned_B == B && h->tuned_H == H && h->tuned_W == W;
       } else {
-        static const char* const cands[3] = {nullptr, "gs2.fwd", "gs3.fwd"};
-        static const bool verbose = getenv("SGA_FORK_VERBOSE") != nullptr;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        HIPCHK(h, hipEventCreate(&e0));
-        HIPCHK(h, hipEventCreate(&e1));
-        float best_ms = 0.f;
-        hipGraphExec_t best = nullptr;
-        const char* best_name = nullptr;
-        for (int c = 0; c < 3; ++c) {
-          h->fork_name = cands[c];
-          hipGraphExec_t ex = capture();
-          if (!ex) continue;
-          float ms = 0.f;
-          bool ok = true;                                            // replays to settle (the first candidate also absorbs
-          const int settle = c == 0 ? 3 : 1;                         // the clock ramp of a fresh run), kTuneReps timed: all
-          for (int r = 0; r < settle && ok; ++r) ok = hipGraphLaunch(ex, st) == hipSuccess;   // of them are iterations of this run
-          ok = ok && hipEventRecord(e0, st) == hipSuccess;
-          for (int r = 0; r < kTuneReps && ok; ++r) ok = hipGraphLaunch(ex, st) == hipSuccess;
-          ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
-               hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
-          if (!ok) {      // a failed launch leaves the run in an unknown state: report it
-            h->retired_graphs.push_back(ex);
-            if (best) h->retired_graphs.push_back(best);
-            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-            h->fork_name = nullptr;
-            HIPCHK(h, hipErrorUnknown);
-          }
-          tuned_done += settle + kTuneReps;
-          if (verbose)
-            fprintf(stderr, "sga fork point %-8s B=%d %dx%d: %.1f us per iteration\n", cands[c] ? cands[c] : "start", B, H, W,
-                    ms * 1000.f / kTuneReps);
-          // the losing candidates are kept until the handle goes (two small executable graphs per tuned geometry): see
-          // sga_handle::retired_graphs
-          if (!best || ms < best_ms) {
-            if (best) h->retired_graphs.push_back(best);
-            best = ex; best_ms = ms; best_name = cands[c];
-          } else {
-            h->retired_graphs.push_back(ex);
-          }
-        }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        h->graph_exec = best;
-        h->fork_name = best_name;
-        h->graph_tuned = best != nullptr;
-        if (best) { h->tuned_B = B; h->tuned_H = H; h->tuned_W = W; h->tuned_name = best_name; }
+        SGACHK(timed_fork_choice(h, st, B, H, W, capture, &h->graph_exec, &tuned_done));
+        h->graph_tuned = h->graph_exec != nullptr;
         if (!h->graph_exec) { h->fork_name = nullptr; h->graph_exec = capture(); }
       }
       if (h->graph_exec) { h->graph_B = B; h->graph_H = H; h->graph_W = W; h->graph_relax = h->relax; }
@@ -2214,9 +2224,10 @@ int sga_set_scale_bound(sga_handle* h, float scale_bound) {
   if (!h || !(scale_bound >= 0.f) || !(scale_bound < 1e30f)) return SGA_ERR_BAD_ARG;
   if (scale_bound == h->scale_bound) return SGA_OK;
   HIPCHK(h, hipDeviceSynchronize());
-  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  if (h->graph_exec) { h->retired_graphs.push_back(h->graph_exec); h->graph_exec = nullptr; }      // (retired: see retired_graphs)
   for (int k = 0; k < 2; ++k)
-    if (h->bb_graph[k]) { (void)hipGraphExecDestroy(h->bb_graph[k]); h->bb_graph[k] = nullptr; }
+    if (h->bb_graph[k]) { h->retired_graphs.push_back(h->bb_graph[k]); h->bb_graph[k] = nullptr; }
+  h->bb_graph_tuned = false;
   h->scale_bound = scale_bound;
   return SGA_OK;
 }
@@ -2250,7 +2261,7 @@ int sga_profile_graph_begin(sga_handle* h, const char* kernel_name) {
     const unsigned long long reset[2] = {~0ull, 0ull};
     HIPCHK(h, hipMemcpy(h->gstamp, reset, sizeof(reset), hipMemcpyHostToDevice));
   }
-  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }      // re-capture with the pair
+  if (h->graph_exec) { h->retired_graphs.push_back(h->graph_exec); h->graph_exec = nullptr; }      // re-capture with the pair
   strncpy(h->gprof_name, kernel_name, sizeof(h->gprof_name) - 1);
   h->gprof_name[sizeof(h->gprof_name) - 1] = 0;
   h->gprof = true; h->gprof_in_graph = false;
@@ -2265,7 +2276,7 @@ int sga_profile_graph_end(sga_handle* h, sga_kernel_stat* out) {
   strncpy(out->name, h->gprof_name, sizeof(out->name) - 1);
   out->launches = h->gprof_n; out->ms_total = h->gprof_ms; out->flops_total = h->gprof_flops;
   h->gprof = false; h->gprof_in_graph = false;
-  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }      // production graph next time
+  if (h->graph_exec) { h->retired_graphs.push_back(h->graph_exec); h->graph_exec = nullptr; }      // production graph next time
   return SGA_OK;
 }
 
@@ -2362,27 +2373,48 @@ int bb_eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_ha
 template <typename F>
 int bb_iterations(sga_handle* h, int stage, const Geom& g, int n, hipStream_t st, F&& enqueue) {
   bool graphed = false;
+  int done = 0;                    // iterations already run by the fork-point candidates
   if (h->use_graph && !h->profiling && n > 0) {
     if (h->bb_graph_B != g.B || h->bb_graph_H != g.H || h->bb_graph_W != g.W) {
+      HIPCHK(h, hipStreamSynchronize(st));
       for (int k = 0; k < 2; ++k)
-        if (h->bb_graph[k]) { (void)hipGraphExecDestroy(h->bb_graph[k]); h->bb_graph[k] = nullptr; }
+        if (h->bb_graph[k]) { h->retired_graphs.push_back(h->bb_graph[k]); h->bb_graph[k] = nullptr; }
       h->bb_graph_B = g.B; h->bb_graph_H = g.H; h->bb_graph_W = g.W;
+      h->bb_graph_tuned = false;
     }
-    if (!h->bb_graph[stage]) {
+    auto capture = [&]() -> hipGraphExec_t {
+      hipGraphExec_t ex = nullptr;
       hipGraph_t graph = nullptr;
       if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         const int rc = enqueue();
         const hipError_t ec = hipStreamEndCapture(st, &graph);
-        if (!(rc == SGA_OK && ec == hipSuccess && graph &&
-              hipGraphInstantiate(&h->bb_graph[stage], graph, nullptr, nullptr, 0) == hipSuccess))
-          h->bb_graph[stage] = nullptr;
+        if (!(rc == SGA_OK && ec == hipSuccess && graph && hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0) == hipSuccess))
+          ex = nullptr;
         if (graph) (void)hipGraphDestroy(graph);
       }
       (void)hipGetLastError();
+      return ex;
+    };
+    // stage 1 (the full step, bb_sga.py:203-236) forks the hyper branch like the plain SGA step: its fork point is timed the
+    // same way (stage 2 is the hyper branch alone: nothing to fork)
+    const bool tune = stage == 0 && h->fork_auto && h->overlap && !h->x3 && n >= 100 && !h->bb_graph_tuned;
+    if (tune && h->bb_graph[0]) {
+      HIPCHK(h, hipStreamSynchronize(st));
+      h->retired_graphs.push_back(h->bb_graph[0]);
+      h->bb_graph[0] = nullptr;
+    }
+    if (!h->bb_graph[stage]) {
+      if (tune) {
+        SGACHK(timed_fork_choice(h, st, g.B, g.H, g.W, capture, &h->bb_graph[0], &done));
+        h->bb_graph_tuned = h->bb_graph[0] != nullptr;
+      } else if (stage == 0 && h->fork_auto) {
+        h->fork_name = (h->tuned_B == g.B && h->tuned_H == g.H && h->tuned_W == g.W) ? h->tuned_name : nullptr;
+      }
+      if (!h->bb_graph[stage]) h->bb_graph[stage] = capture();
     }
     graphed = h->bb_graph[stage] != nullptr;
   }
-  for (int it = 0; it < n; ++it) {
+  for (int it = done; it < n; ++it) {
     if (graphed) HIPCHK(h, hipGraphLaunch(h->bb_graph[stage], st));
     else SGACHK(enqueue());
   }
