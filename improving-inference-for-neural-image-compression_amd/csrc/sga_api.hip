@@ -158,6 +158,7 @@ struct sga_handle {
   // ---- cached step graph ----
   hipGraphExec_t graph_exec = nullptr;
   bool side_lowfoot = false;       // SGA_SIDE_LOWFOOT=1: the hyper branch's 64-row launches in the 33-KB form (fit beside gs2.bwd)
+  int fork_delay_us = 0;           // SGA_FORK_DELAY_US (experiment)
   bool in_hyper = false;           // the launches being enqueued belong to the hyper branch
   int side_target = 384;           // split-K target (workgroups per launch) of the hyper branch (SGA_SIDE_TARGET; 0: the main chain's 512)
   bool side_last = true;           // graph capture: create the hyper branch's nodes after the main chain's (SGA_SIDE_LAST=0: before)
@@ -1013,6 +1014,8 @@ int hyper_branch_impl(sga_handle* h, const Geom& g, bool with_grad, hipStream_t 
   const int B = g.B, C = h->C;
   const float il = inv_ln2_hw(g);
   if (part != 2) {
+  // experiment (SGA_FORK_DELAY_US): hold the branch back for a fixed time after its fork point -- a fork "inside" a launch
+  if (h->fork_delay_us > 0 && st == h->sB) HIPCHK(h, launch_spin(h->fork_delay_us, st));
   if (density)   // bits-back: prior DENSITY (bb_sga.py:105-106)
     HIPCHK(h, launch_factorized_pdf(h->zt.p, h->eb_packed, h->ctx, B, g.zh * g.zw, C, il, h->sums,
                                     with_grad ? h->g_zt_eb.p : nullptr, nullptr, nullptr, st));
@@ -1635,6 +1638,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   if (C / 32 != 2 && C / 32 != 4 && C / 32 != 6 && C / 32 != 8) h->fused_gdn = false;
   env = getenv("SGA_KEEP_U");
   h->keep_u = env && env[0] == '1';
+  env = getenv("SGA_FORK_DELAY_US");
+  if (env) h->fork_delay_us = atoi(env);
   env = getenv("SGA_SIDE_LOWFOOT");
   h->side_lowfoot = env && env[0] == '1';
   env = getenv("SGA_MAIN_WAVE_PRIO");
