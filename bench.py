@@ -310,7 +310,8 @@ def main():
                                    f"batch of {B} synthetic {H}x{W} images per GPU",
                        "images_per_step": world * B, "sga_iterations": args.its,
                        "weights": "synthetic (make_synthetic_weights seed 0)",
-                       "parallelism": f"images sharded over {world} GPU(s), RCCL all_gather of metrics"},
+                       "parallelism": f"images sharded over {world} GPU(s), RCCL all_gather of metrics",
+                       "hyper_branch_fork_point": codec.fork_point()},
             "precision": args.precision, "input": args.input,
             "other_input": other_input,
             "roofline": roofline,

@@ -102,6 +102,7 @@ SYMBOLS["sga_profile_begin"] = (_I, [_P])
 SYMBOLS["sga_profile_end"] = (_I, [_P, C.POINTER(SgaKernelStat), _I, C.POINTER(_I)])
 SYMBOLS["sga_profile_graph_begin"] = (_I, [_P, C.c_char_p])
 SYMBOLS["sga_profile_graph_end"] = (_I, [_P, C.POINTER(SgaKernelStat)])
+SYMBOLS["sga_get_fork_point"] = (_I, [_P, C.c_char_p, _I])
 
 SYMBOLS["sga_ec_y_symbols"] = (_I, [_P, _P, _P, _I64, _P, _I, _I, _I, _P, _P, _P, _P, _P])
 SYMBOLS["sga_ec_z_symbols"] = (_I, [_P, _I64, _I, _P, _P, _P, _P])

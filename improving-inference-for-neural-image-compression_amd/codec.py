@@ -571,6 +571,12 @@ class SGACodec:
         return dict(name=st.name.decode(), launches=int(st.launches), ms_total=float(st.ms_total),
                     flops_total=float(st.flops_total))
 
+    def fork_point(self):
+        """Where the hyper branch of the cached step graph is forked (timed per geometry)."""
+        buf = C.create_string_buffer(32)
+        self._chk(self.lib.sga_get_fork_point(self.handle, buf, 32), "sga_get_fork_point")
+        return buf.value.decode()
+
     # ---- operator surface (unit parity) --------------------------------------------------------
     def layer_fwd(self, layer: str, inp):
         inp = self._t(inp)

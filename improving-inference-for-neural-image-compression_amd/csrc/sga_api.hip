@@ -2274,6 +2274,14 @@ int sga_profile_graph_begin(sga_handle* h, const char* kernel_name) {
   return SGA_OK;
 }
 
+int sga_get_fork_point(const sga_handle* h, char* name, int name_len) {
+  if (!h || !name || name_len <= 0) return SGA_ERR_BAD_ARG;
+  const char* s = (h->graph_tuned || h->bb_graph_tuned) ? (h->fork_name ? h->fork_name : "start") : (h->fork_auto ? "untimed" : "pinned");
+  strncpy(name, s, (size_t)name_len - 1);
+  name[name_len - 1] = 0;
+  return SGA_OK;
+}
+
 int sga_profile_graph_end(sga_handle* h, sga_kernel_stat* out) {
   if (!h || !out) return SGA_ERR_BAD_ARG;
   HIPCHK(h, hipDeviceSynchronize());

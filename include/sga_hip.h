@@ -326,6 +326,10 @@ int sga_profile_end(sga_handle* h, sga_kernel_stat* out, int max_out, int* n_out
  * drops the instrumented graph. */
 int sga_profile_graph_begin(sga_handle* h, const char* kernel_name);
 int sga_profile_graph_end(sga_handle* h, sga_kernel_stat* out);
+/* The main-chain launch before which the hyper branch of the cached step graph is forked ("start", "gs2.fwd", "gs3.fwd"):
+ * chosen by time, once per geometry, by the first sga_run_steps call with >= 100 iterations (it changes no
+ * bit of any result); "untimed" while no such call has been made.  Reporting only. */
+int sga_get_fork_point(const sga_handle* h, char* name, int name_len);
 
 #ifdef __cplusplus
 }

@@ -238,7 +238,13 @@ def test_results_do_not_depend_on_the_schedule(monkeypatch):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         c = SGACodec(w, C, B, H, W)
+        before = c.fork_point()
         out = c.run(x, 0.01, its=130, seed=4)            # >= 100 iterations: the timed fork point when nothing pins it
+        after = c.fork_point()
+        if not env:                                      # sga_get_fork_point: reporting only
+            assert before == "untimed" and after in ("start", "gs2.fwd", "gs3.fwd"), (before, after)
+        elif "SGA_FORK_AT" in env or "SGA_FORK_NAME" in env:
+            assert before == after == "pinned", (before, after)
         g = c.step_grads(x, out[0], out[1], 0.3, 0.01, seed=2, it=7)
         c.close()
         return out, g
