@@ -14,4 +14,5 @@ import os as _os
 # package is imported before that; an explicit setting by the user wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
-from .weights import make_synthetic_weights, layer_shapes, weights_digest, check_weights  # noqa: F401
+from .weights import (make_synthetic_weights, layer_shapes, weights_digest, check_weights,  # noqa: F401
+                      make_lowpass_images, load_weights_npz, save_weights_npz)

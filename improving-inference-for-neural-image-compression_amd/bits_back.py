@@ -109,6 +109,65 @@ class _PriorGrid:
         self.lens, self.offs = np.asarray(lens, np.int32), np.asarray(offs, np.int32)
 
 
+def quantise_pmf_closed(pmf: np.ndarray, tail_lo: float, tail_hi: float) -> np.ndarray:
+    """A CDF WITHOUT escape mass: the probability outside the table is folded into its two edge bins, every regular symbol
+    keeps frequency >= 1 and the regular symbols sum to exactly 1 << 16; the escape entry the rANS primitives expect at
+    the end of a table has frequency 0 (never popped: no state value maps to it)."""
+    p = np.array(pmf, np.float64)
+    p[0] += max(tail_lo, 0.0)
+    p[-1] += max(tail_hi, 0.0)
+    p = p / p.sum()
+    f = np.maximum(np.round(p * ec.TOTAL).astype(np.int64), 1)
+    diff = int(ec.TOTAL - f.sum())
+    order = np.argsort(-f)
+    i = 0
+    while diff != 0:
+        j = order[i % f.size]
+        step = 1 if diff > 0 else -1
+        if f[j] + step >= 1:
+            f[j] += step
+            diff -= step
+        i += 1
+    cdf = np.zeros(f.size + 2, np.uint32)
+    cdf[1:-1] = np.cumsum(f)
+    cdf[-1] = cdf[-2]
+    assert cdf[-1] == ec.TOTAL
+    return cdf
+
+
+class _PosteriorTables:
+    """The tables Q(z | y) is sampled from and coded back with: the conditional's family (scale level x mean-fraction bin,
+    unit bins, entropy_coding.EntropyCoder) WITHOUT escape symbols.  A `pop` draws a symbol from whatever bits are on the
+    stack; with the conditional's own tables it lands in the escape symbol (frequency >= 1 of 65536 in all 512 tables) once
+    in ~2^16 elements and then reads 32 raw stack bits as the value -- |z_bar| ~ 2^30 / 8, one image in four at Kodak size
+    (18 432 elements).  Here every state value maps to a regular symbol.  Built on the host in float64 (both sides must
+    build identical tables; they do not depend on the weights)."""
+
+    def __init__(self, yq: ec.EntropyCoder):
+        import math
+        tables, lens, offs = [], [], []
+        for s in yq.scale_table:
+            R = int(math.ceil(6.0 * s + 1.0))
+            for j in range(ec.MEAN_BINS):
+                f = (j + 0.5) / ec.MEAN_BINS - 0.5
+                r = np.arange(-R, R + 1, dtype=np.float64)
+                up, lo = ec._phi((r + 0.5 - f) / s), ec._phi((r - 0.5 - f) / s)
+                tables.append(quantise_pmf_closed(up - lo, float(lo[0]), float(1.0 - up[-1])))
+                lens.append(r.size + 1)
+                offs.append(-R)
+        self.stride = max(t.size for t in tables)
+        self.cdf = np.zeros((len(tables), self.stride), np.uint32)
+        for i, t in enumerate(tables):
+            self.cdf[i, :t.size] = t
+            self.cdf[i, t.size:] = ec.TOTAL
+        self.lens, self.offs = np.asarray(lens, np.int32), np.asarray(offs, np.int32)
+        self.tab0 = yq.y_tab0
+
+    def in_range(self, sym, tab) -> bool:
+        i = sym.astype(np.int64) - self.offs[tab]
+        return bool(((i >= 0) & (i < self.lens[tab] - 1)).all())
+
+
 class BitsBackCoder:
     def __init__(self, codec, delta: float = 1.0 / 8, k_max: int = 1024):
         """codec: an SGACodec created with bits_back=True (its HIP layers give h_s, its sga_bb_refine the posterior)."""
@@ -116,6 +175,7 @@ class BitsBackCoder:
             raise ValueError("bits-back coding needs a codec of the mbt2018_bb model (bits_back=True)")
         self.codec, self.delta = codec, float(delta)
         self.yq = codec._entropy_coder()                    # unit-bin Gaussian tables: p(y | z) and, on z / delta, Q(z | y)
+        self.q = _PosteriorTables(self.yq)                  # the same family without escape symbols (see _PosteriorTables)
         self.prior = _PriorGrid(codec._weights_for_ec, self.delta, k_max)
         self.C = codec.C
 
@@ -124,7 +184,8 @@ class BitsBackCoder:
         mean, logvar = zml[..., :self.C], zml[..., self.C:]
         u_mean = (mean / self.delta).astype(np.float32)
         u_sigma = (np.exp(0.5 * logvar.astype(np.float64)) / self.delta).astype(np.float32)
-        return self.yq._y_symbols(None, u_mean, u_sigma)    # (r0 = rint(u_mean), table)
+        r0, tab = self.yq._y_symbols(None, u_mean, u_sigma)
+        return r0, tab - self.q.tab0                        # (r0 = rint(u_mean), table index in self.q)
 
     def _y_tables(self, z_bar, yh, yw):
         mu, sigma = self.codec.hyper_synthesis(self.codec._t(z_bar), yh, yw)
@@ -146,7 +207,7 @@ class BitsBackCoder:
         st = AnsStack(initial, capacity=init_bytes + 16 + 8 * (y_hat.size + nz))
         bits0 = st.bits()
         r0q, tabq = self._q_tables(zml)
-        k = st.pop(self.yq, tabq).reshape(r0q.shape) + r0q                              # 1. z_bar ~ Q
+        k = st.pop(self.q, tabq).reshape(r0q.shape) + r0q                               # 1. z_bar ~ Q (escape-free tables)
         bits1 = st.bits()
         z_bar = (k.astype(np.float32) * np.float32(self.delta)).reshape(zml[..., :self.C].shape)
         r0y, taby = self._y_tables(z_bar, y_hat.shape[1], y_hat.shape[2])
@@ -170,5 +231,8 @@ class BitsBackCoder:
         y_hat = (st.pop(self.yq, taby).reshape(y_shape) + r0y).astype(np.float32)         # 2. y | z_bar
         zml = self.codec.bb_refine(y_hat, H, W, r_its=r_its, r_lr=r_lr, seed=seed, loss_scale=loss_scale)
         r0q, tabq = self._q_tables(zml.cpu().numpy())
-        st.push(self.yq, k - r0q, tabq)                                                   # 3. give the bits back
+        if not self.q.in_range((k - r0q).reshape(-1), tabq.reshape(-1)):
+            raise ValueError("bits-back decode: z_bar lies outside the posterior's table -- the receiver's q(z | y) is not "
+                             "the sender's (other weights, seed, r_its or r_lr?)")
+        st.push(self.q, k - r0q, tabq)                                                    # 3. give the bits back
         return y_hat, z_bar, st.tobytes()[4:], st.x.value

@@ -131,6 +131,8 @@ struct sga_handle {
   bool fork_auto = true;           // the fork point is chosen per geometry by timing the candidates (off when SGA_FORK_AT is set)
   bool graph_tuned = false;        // the cached step graph was built with a timed fork point
   bool bb_graph_tuned = false;     // ... and the bits-back stage-1 graph
+  bool x3_fork = false;            // bf16x3 mode with the hyper branch on the second stream (SGA_X3_FORK=1; see DESIGN_EXPERIMENTS.md A.8)
+  bool drop_destroy = false;       // drop_graph(): destroy a dropped executable graph at once (SGA_GRAPH_DROP=destroy) or retire it
   std::vector<hipGraphExec_t> retired_graphs;   // candidate graphs that lost the timing: destroyed with the handle (experiment:
                                    // destroying them while their sibling is in use crashed the process in the full test suite)
   int tuned_B = 0, tuned_H = 0, tuned_W = 0;   // geometry the last timed choice (tuned_name) was made for: graphs of that
@@ -1166,7 +1168,7 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
     h->cur_part = &h->part;
     return rc;
   }
-  const bool fork = h->overlap && !h->x3 && !h->profiling && do_synth;
+  const bool fork = h->overlap && (!h->x3 || h->x3_fork) && !h->profiling && do_synth;
   if (!fork) {
     h->cur_part = &h->part;
     SGACHK(hyper_branch(h, g, with_grad, st, density));
@@ -1272,6 +1274,16 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
   return SGA_OK;
 }
 
+// Disposal of an executable graph that is dropped in mid-life (a losing fork-point candidate, a geometry change, a changed
+// sigma bound, the stamped graph of sga_profile_graph_*).  Policy (sga_handle::drop_destroy, SGA_GRAPH_DROP=destroy|retire):
+// destroy it now -- the caller has synchronised the stream(s) its replays ran on -- or keep it until sga_destroy.
+void drop_graph(sga_handle* h, hipGraphExec_t& ex) {
+  if (!ex) return;
+  if (h->drop_destroy) (void)hipGraphExecDestroy(ex);
+  else h->retired_graphs.push_back(ex);
+  ex = nullptr;
+}
+
 // The fork point of the hyper branch, chosen by time: captures one step graph per candidate (`capture` records
 // one iteration under the current h->fork_name), replays each a few times -- on the caller's live state: the replays are
 // iterations of the run and are counted in *done -- and returns the fastest; the others are retired (sga_handle::retired_graphs).
@@ -1299,8 +1311,8 @@ int timed_fork_choice(sga_handle* h, hipStream_t st, int B, int H, int W, Cap&& 
     ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
          hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
     if (!ok) {      // a failed launch leaves the run in an unknown state: report it
-      h->retired_graphs.push_back(ex);
-      if (best) h->retired_graphs.push_back(best);
+      drop_graph(h, ex);
+      drop_graph(h, best);
       (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
       h->fork_name = nullptr;
       HIPCHK(h, hipErrorUnknown);
@@ -1312,10 +1324,10 @@ int timed_fork_choice(sga_handle* h, hipStream_t st, int B, int H, int W, Cap&& 
     // the losing candidates are kept until the handle goes (two small executable graphs per tuned geometry): see
     // sga_handle::retired_graphs
     if (!best || ms < best_ms) {
-      if (best) h->retired_graphs.push_back(best);
+      drop_graph(h, best);
       best = ex; best_ms = ms; best_name = cands[c];
     } else {
-      h->retired_graphs.push_back(ex);
+      drop_graph(h, ex);
     }
   }
   (void)hipEventDestroy(e0);
@@ -1613,6 +1625,10 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     if (dev_alloc(h, &p, (size_t)kMaxIts * 16 * 8) != SGA_OK) return fail(SGA_ERR_NOMEM);
     h->dump = (unsigned long long*)p;
   }
+  env = getenv("SGA_X3_FORK");
+  h->x3_fork = env && env[0] == '1';
+  env = getenv("SGA_GRAPH_DROP");
+  if (env) h->drop_destroy = strcmp(env, "destroy") == 0;
   env = getenv("SGA_SPLIT256");
   h->split256 = !(env && env[0] == '0');
   env = getenv("SGA_BM256");
@@ -1964,8 +1980,7 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
         // replays of the old graph may still be queued (a short run followed at once by a long one): let them finish
         // before the executable graph is destroyed
         HIPCHK(h, hipStreamSynchronize(st));
-        h->retired_graphs.push_back(h->graph_exec);      // retired, not destroyed (see retired_graphs): an executable graph of
-        h->graph_exec = nullptr;                         // ~30 kernel nodes per geometry change, freed with the handle
+        drop_graph(h, h->graph_exec);
       }
       h->graph_tuned = false;
       if (!tune) {
@@ -2229,9 +2244,8 @@ int sga_set_scale_bound(sga_handle* h, float scale_bound) {
   if (!h || !(scale_bound >= 0.f) || !(scale_bound < 1e30f)) return SGA_ERR_BAD_ARG;
   if (scale_bound == h->scale_bound) return SGA_OK;
   HIPCHK(h, hipDeviceSynchronize());
-  if (h->graph_exec) { h->retired_graphs.push_back(h->graph_exec); h->graph_exec = nullptr; }      // (retired: see retired_graphs)
-  for (int k = 0; k < 2; ++k)
-    if (h->bb_graph[k]) { h->retired_graphs.push_back(h->bb_graph[k]); h->bb_graph[k] = nullptr; }
+  drop_graph(h, h->graph_exec);
+  for (int k = 0; k < 2; ++k) drop_graph(h, h->bb_graph[k]);
   h->bb_graph_tuned = false;
   h->scale_bound = scale_bound;
   return SGA_OK;
@@ -2266,7 +2280,7 @@ int sga_profile_graph_begin(sga_handle* h, const char* kernel_name) {
     const unsigned long long reset[2] = {~0ull, 0ull};
     HIPCHK(h, hipMemcpy(h->gstamp, reset, sizeof(reset), hipMemcpyHostToDevice));
   }
-  if (h->graph_exec) { h->retired_graphs.push_back(h->graph_exec); h->graph_exec = nullptr; }      // re-capture with the pair
+  drop_graph(h, h->graph_exec);      // re-capture with the pair
   strncpy(h->gprof_name, kernel_name, sizeof(h->gprof_name) - 1);
   h->gprof_name[sizeof(h->gprof_name) - 1] = 0;
   h->gprof = true; h->gprof_in_graph = false;
@@ -2289,7 +2303,7 @@ int sga_profile_graph_end(sga_handle* h, sga_kernel_stat* out) {
   strncpy(out->name, h->gprof_name, sizeof(out->name) - 1);
   out->launches = h->gprof_n; out->ms_total = h->gprof_ms; out->flops_total = h->gprof_flops;
   h->gprof = false; h->gprof_in_graph = false;
-  if (h->graph_exec) { h->retired_graphs.push_back(h->graph_exec); h->graph_exec = nullptr; }      // production graph next time
+  drop_graph(h, h->graph_exec);      // production graph next time
   return SGA_OK;
 }
 
@@ -2390,8 +2404,7 @@ int bb_iterations(sga_handle* h, int stage, const Geom& g, int n, hipStream_t st
   if (h->use_graph && !h->profiling && n > 0) {
     if (h->bb_graph_B != g.B || h->bb_graph_H != g.H || h->bb_graph_W != g.W) {
       HIPCHK(h, hipStreamSynchronize(st));
-      for (int k = 0; k < 2; ++k)
-        if (h->bb_graph[k]) { h->retired_graphs.push_back(h->bb_graph[k]); h->bb_graph[k] = nullptr; }
+      for (int k = 0; k < 2; ++k) drop_graph(h, h->bb_graph[k]);
       h->bb_graph_B = g.B; h->bb_graph_H = g.H; h->bb_graph_W = g.W;
       h->bb_graph_tuned = false;
     }
@@ -2413,8 +2426,7 @@ int bb_iterations(sga_handle* h, int stage, const Geom& g, int n, hipStream_t st
     const bool tune = stage == 0 && h->fork_auto && h->overlap && !h->x3 && n >= 100 && !h->bb_graph_tuned;
     if (tune && h->bb_graph[0]) {
       HIPCHK(h, hipStreamSynchronize(st));
-      h->retired_graphs.push_back(h->bb_graph[0]);
-      h->bb_graph[0] = nullptr;
+      drop_graph(h, h->bb_graph[0]);
     }
     if (!h->bb_graph[stage]) {
       if (tune) {

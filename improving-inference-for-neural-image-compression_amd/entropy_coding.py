@@ -298,17 +298,28 @@ def pack(x_shape, y_shape, z_shape, z_bytes: bytes, y_bytes: bytes, table_mode: 
 
 
 def unpack(blob: bytes, with_tables: bool = False):
-    if blob[:4] != MAGIC:
+    """Inverse of `pack`.  Every malformed input -- wrong magic, another format version, a truncated header, stream lengths
+    that run past the blob -- raises ValueError (never struct.error, never silently short streams)."""
+    if len(blob) < 4 or blob[:4] != MAGIC:
         raise ValueError("not an SGAC stream")
+    if len(blob) < 12:
+        raise ValueError("corrupt stream: truncated SGAC header")
     version, table_mode, _, table_crc = struct.unpack("<BBHI", blob[4:12])
     if version != FORMAT_VERSION:
-        raise ValueError(f"SGAC stream format {version}, this build reads format {FORMAT_VERSION}")
+        raise ValueError(f"SGAC stream format {version}, this build reads format {FORMAT_VERSION} "
+                         + ("(format 1, round 2, carried no table fingerprint: re-encode the latents)" if version == 1 else ""))
+    if len(blob) < 56 + 8:
+        raise ValueError("corrupt stream: truncated SGAC header")
     v = struct.unpack("<3I4I4I", blob[12:56])
     x_shape, y_shape, z_shape = v[:3], v[3:7], v[7:11]
     p = 56
     (nz,) = struct.unpack("<I", blob[p:p + 4]); p += 4
+    if p + nz + 4 > len(blob):
+        raise ValueError("corrupt stream: z stream length runs past the end")
     z_bytes = blob[p:p + nz]; p += nz
     (ny,) = struct.unpack("<I", blob[p:p + 4]); p += 4
+    if p + ny != len(blob):
+        raise ValueError("corrupt stream: y stream length does not match the blob")
     y_bytes = blob[p:p + ny]
     if with_tables:
         return x_shape, y_shape, z_shape, z_bytes, y_bytes, table_mode, table_crc

@@ -127,6 +127,37 @@ def make_synthetic_weights(C: int = 192, seed: int = 0, bb: bool = False) -> dic
     return w
 
 
+def make_lowpass_images(B: int, H: int, W: int, seed: int = 0, passes: int = 2, k: int = 9) -> np.ndarray:
+    """Deterministic "natural-ish" synthetic images: uniform noise, `passes` k x k box blurs with
+    reflected borders, every image channel stretched back to [0, 1].  float32 [B,H,W,3].  Pure numpy (float64 sums), so
+    the GPU box, the build container and the fixture generators produce the same pixels."""
+    x = np.random.RandomState(seed).rand(B, H, W, 3)
+    r = k // 2
+    for _ in range(passes):
+        for axis, n in ((1, H), (2, W)):
+            pad = [(0, 0)] * 4
+            pad[axis] = (r, r)
+            c = np.cumsum(np.pad(x, pad, mode="reflect"), axis=axis)
+            c = np.concatenate([np.zeros_like(np.take(c, [0], axis=axis)), c], axis=axis)
+            x = (np.take(c, range(k, n + k), axis=axis) - np.take(c, range(0, n), axis=axis)) / k
+    lo, hi = x.min(axis=(1, 2), keepdims=True), x.max(axis=(1, 2), keepdims=True)
+    return ((x - lo) / (hi - lo)).astype(np.float32)
+
+
+def load_weights_npz(path: str) -> dict:
+    """Effective tensors stored by `save_weights_npz` (float16-representable values kept as float16 on disk)."""
+    with np.load(path) as f:
+        return {k: f[k].astype(np.float32) for k in f.files}
+
+
+def save_weights_npz(path: str, w: dict) -> dict:
+    """Rounds every tensor to float16-representable values (that IS the stored model), writes them compressed and returns
+    the float32 dict a later `load_weights_npz` yields."""
+    q = {k: np.asarray(v, np.float32).astype(np.float16) for k, v in w.items()}
+    np.savez_compressed(path, **q)
+    return {k: v.astype(np.float32) for k, v in q.items()}
+
+
 def weights_digest(w: dict) -> str:
     """sha256 over all tensors in key order: committed in tests instead of the tensors."""
     h = hashlib.sha256()

@@ -104,3 +104,69 @@ def test_ans_stack_push_and_pop_are_inverse(coder):
     assert st.tobytes()[4:] == init and st.x.value == 1 << 23
     with pytest.raises(RuntimeError):
         AnsStack(b"", 64).pop(coder, tab)                               # nothing to sample from
+
+
+def test_unpack_refuses_malformed_blobs(coder):
+    """a truncated or inconsistent container is a ValueError, never struct.error or silently short streams."""
+    blob = ec.pack((1, 64, 64), (1, 4, 4, 64), (1, 1, 1, 64), b"zz", b"yyyy", 1, 0x1234)
+    assert ec.unpack(blob, with_tables=True)[3:] == (b"zz", b"yyyy", 1, 0x1234)
+    for bad in (b"", b"SGA", blob[:8], blob[:40], blob[:57], blob[:-1], blob + b"\0", blob[:56] + b"\xff\xff\xff\x7f" + blob[60:]):
+        with pytest.raises(ValueError):
+            ec.unpack(bad)
+    with pytest.raises(ValueError, match="format 1"):
+        ec.unpack(blob[:4] + b"\x01" + blob[5:])
+
+
+def test_host_coder_equals_the_rans_oracle_byte_for_byte(coder):
+    """csrc_cpu/rans.c against oracle/rans_ref.py (the published rANS recurrences in Python integers): identical bytes for
+    identical tables, escapes included, and the oracle decodes what the host coder wrote (and vice versa)."""
+    from oracle import rans_ref
+    rng = np.random.RandomState(5)
+    n = 3000
+    tab = rng.randint(0, coder.cdf.shape[0], n).astype(np.int32)
+    span = coder.lens[tab] - 1
+    sym = (coder.offs[tab] + (rng.rand(n) * span).astype(np.int32)).astype(np.int32)
+    sym[::97] = rng.randint(-70000, 70000, sym[::97].size)               # far outside every table: escapes
+    sym[5], sym[6] = -2 ** 31 + 1, 2 ** 31 - 1
+    data = coder._run_encode(sym, tab)
+    bb, block, payload = ec.unframe_blocks(data)
+    sizes, ref_payload = rans_ref.encode_blocked(sym.tolist(), tab.tolist(), block, coder.cdf, coder.lens, coder.offs)
+    assert sizes == bb.tolist() and ref_payload == payload
+    assert rans_ref.decode_blocked(payload, bb.tolist(), tab.tolist(), block, coder.cdf, coder.lens, coder.offs) == sym.tolist()
+    assert np.array_equal(coder._run_decode(ec.frame_blocks(np.asarray(sizes, np.uint32), ref_payload, block), tab), sym)
+    # code length: within 1 % + the per-block flush of the ideal length of the quantised tables
+    idx = sym.astype(np.int64) - coder.offs[tab]
+    esc = (idx < 0) | (idx >= coder.lens[tab] - 1)
+    idx = np.where(esc, coder.lens[tab] - 1, idx)
+    f = coder.cdf[tab, idx + 1].astype(np.float64) - coder.cdf[tab, idx]
+    ideal = -np.log2(f / ec.TOTAL).sum() + 32.0 * esc.sum()
+    assert ideal <= 8 * len(payload) <= ideal * 1.01 + 64 * len(sizes)
+
+
+def test_bits_back_posterior_tables_have_no_escape(coder):
+    """ADVICE r3 (bits_back.py): sampling z_bar ~ Q by POPPING from the stack must never land in an escape symbol -- with
+    the conditional's own tables (escape frequency >= 1 / 65536 in every table) it does once in ~2^16 elements, i.e. in one
+    Kodak-size image (18 432 elements of z) out of four, and then reads 32 raw stack bits as the value.  The posterior's
+    tables fold the tails into the edge bins: every 16-bit state slot maps to a regular symbol, and a pop / push round
+    trip over 10 Kodak images' worth of elements returns the stack bit for bit."""
+    from sga_amd import bits_back as bb
+    q = bb._PosteriorTables(coder)
+    for t in range(q.cdf.shape[0]):
+        c = q.cdf[t, :q.lens[t] + 1].astype(np.int64)
+        d = np.diff(c)
+        assert c[0] == 0 and c[-1] == ec.TOTAL and (d[:-1] >= 1).all() and d[-1] == 0
+    esc = coder.cdf[coder.y_tab0:, :].astype(np.int64)
+    assert all(esc[t, coder.lens[coder.y_tab0 + t]] - esc[t, coder.lens[coder.y_tab0 + t] - 1] >= 1 for t in range(512))
+    n = 184320
+    init = np.random.RandomState(0).bytes(2 * n)
+    st = bb.AnsStack(init, 2 * n + 16 + 8 * n)
+    tab = np.random.RandomState(1).randint(0, 512, n).astype(np.int32)
+    before = st.tobytes()
+    sym = st.pop(q, tab)
+    assert q.in_range(sym, tab) and np.abs(sym).max() <= 1537          # never a raw 32-bit value
+    # the same draw through the conditional's OWN tables does hit escapes at this size
+    st2 = bb.AnsStack(init, 2 * n + 16 + 8 * n)
+    sym2 = st2.pop(coder, tab + coder.y_tab0)
+    assert np.abs(sym2).max() > 1 << 20
+    st.push(q, sym, tab)
+    assert st.tobytes() == before

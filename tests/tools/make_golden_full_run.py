@@ -48,6 +48,19 @@ CFGS = {
     # (tests/test_gpu_acceptance.py::test_trace_at_the_benchmarked_geometry); ~30 min on one core.
     "cfg2trace": dict(C=192, B=8, H=256, W=256, its=300, lmbda=0.01, x_seed=11, weight_seed=0, scale_bound=0.0, t0=50,
                       annealing_rate=5e-3, trace=True, seeds=[0]),
+    # The same run as seed 0 of "cfg2" (PRODUCTION schedule: t0 = 700, rate 1e-3, all 2000 iterations) with its per-iteration
+    # trace kept: tests/test_gpu_acceptance.py::test_trace_2000_at_the_production_schedule follows it step by step up to the
+    # iteration at which the HIP and the oracle trajectories first differ in a floor / ceil decision.  ~2.3 h on one core.
+    "cfg2trace2000": dict(C=192, B=8, H=256, W=256, its=2000, lmbda=0.01, x_seed=11, weight_seed=0, scale_bound=0.0,
+                          trace=True, seeds=[0]),
+    # A TRAINED-LIKE operating point (tests/tools/fit_weights.py -> tests/golden/fitted_weights_c64.npz: ~0.5 bpp / 30 dB on
+    # low-pass noise, most of y_hat at 0, predicted scales straddling 0.11), in BOTH sigma-bound modes: raw sigma (what
+    # sga.py:130-133 executes on an un-built tfc layer) and 0.11 (a built layer, mbt2018.py:77-80).  This is where the two
+    # modes differ by far more than the tolerance and where first contact with TensorFlow will land.
+    "fitted": dict(C=64, B=4, H=64, W=64, its=2000, lmbda=0.01, x_seed=21, weight_seed=0, scale_bound=0.0,
+                   weights="fitted_c64", inputs="lowpass", seeds=list(range(32))),
+    "fitted_b011": dict(C=64, B=4, H=64, W=64, its=2000, lmbda=0.01, x_seed=21, weight_seed=0, scale_bound=0.11,
+                        weights="fitted_c64", inputs="lowpass", seeds=list(range(32))),
     # CONTROL for the statistical criterion: the small set's inputs and Philox seeds through the float64 oracle.  The
     # float32-vs-float64 ORACLE difference is what "a different rounding of the same arithmetic" does to a 2000-step run;
     # tests/test_oracle.py asserts it has the spread the GPU acceptance test tolerates
@@ -65,7 +78,17 @@ OUT = os.path.join(ROOT, "tests", "golden", "full_run_oracle%s.json" % ("_" + NA
 
 def make_inputs(cfg):
     import numpy as np
+    if cfg.get("inputs") == "lowpass":
+        import sga_amd
+        return sga_amd.make_lowpass_images(cfg["B"], cfg["H"], cfg["W"], seed=cfg["x_seed"])
     return np.random.RandomState(cfg["x_seed"]).rand(cfg["B"], cfg["H"], cfg["W"], 3).astype(np.float32)
+
+
+def make_weights(cfg):
+    import sga_amd
+    if cfg.get("weights"):
+        return sga_amd.load_weights_npz(os.path.join(ROOT, "tests", "golden", "fitted_weights_%s.npz" % cfg["weights"].split("_")[1]))
+    return sga_amd.make_synthetic_weights(cfg["C"], seed=cfg["weight_seed"], bb=bool(cfg.get("bb")))
 
 
 def one_seed(seed):
@@ -74,7 +97,7 @@ def one_seed(seed):
     torch.set_num_threads(1)
     import sga_amd
     from oracle.sga_oracle import SGAOracle
-    w = sga_amd.make_synthetic_weights(CFG["C"], seed=CFG["weight_seed"], bb=bool(CFG.get("bb")))
+    w = make_weights(CFG)
     x = make_inputs(CFG)
     t = time.time()
     orc = SGAOracle(w, dtype=getattr(torch, CFG.get("dtype", "float32")), scale_bound=CFG["scale_bound"])
@@ -89,7 +112,8 @@ def one_seed(seed):
                est_bpp=m["est_bpp"].astype(np.float64).tolist(), psnr=m["psnr"].astype(np.float64).tolist(),
                est_y_bpp=m["est_y_bpp"].astype(np.float64).tolist(),
                est_z_bpp=m["est_z_bpp"].astype(np.float64).tolist(), mse=m["mse"].astype(np.float64).tolist(),
-               y_hat_sum=float(np.abs(y_hat).sum()), z_hat_sum=float(np.abs(z_hat).sum()))
+               y_hat_sum=float(np.abs(y_hat).sum()), z_hat_sum=float(np.abs(z_hat).sum()),
+               frac_zero_y_hat=float((y_hat == 0).mean()))
     if CFG.get("bb"):
         out["est_bpp_back"] = m["est_bpp_back"].astype(np.float64).tolist()
     if CFG.get("trace"):
