@@ -10,6 +10,13 @@ import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libsga_hip.so")
+# the laboratory build (`make EXPERIMENTS=1`): the same library plus every ablation / placement switch of
+# DESIGN_EXPERIMENTS.md (SGA_FUSED_GDN, SGA_KEEP_U, SGA_GS3_GEMM, SGA_FORK_AT, ...).  The product library contains none of them.
+LAB_LIB_PATH = os.path.join(_PKG_DIR, "libsga_hip_lab.so")
+# the run-time knobs the PRODUCT library reads from the environment; tests/test_host.py checks
+# the strings of the built library against this list
+PRODUCT_ENV_KNOBS = ("SGA_PRECISION", "SGA_NO_GRAPH", "SGA_NO_OVERLAP", "SGA_NO_SPLITK", "SGA_FORK_NAME", "SGA_FORK_VERBOSE",
+                     "SGA_PROFILE_BY_LAYER", "SGA_GRAPH_DROP", "SGA_X3_FORK", "SGA_X3_VARIANTS")
 
 SGA_ABI_VERSION = 3
 
@@ -66,6 +73,8 @@ SYMBOLS = {
     "sga_quantize_centered": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "sga_eval": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "sga_base_compress": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "sga_base_compress_bound": (_I, [_P, _P, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
+    "sga_op_gaussian_likelihood_bound": (_I, [_P, _P, _P, _P, _I64, _F, _P, _P, _P, _P, _P]),
     "sga_op_layer_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     "sga_op_layer_bwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P]),
     "sga_op_sample": (_I, [_P, _P, _P, _I64, _F, _P, _P, _P]),
@@ -111,6 +120,15 @@ SYMBOLS["sga_ec_compact"] = (_I, [_P, _I, _P, _P, _I, _P, _P])
 SYMBOLS["sga_ec_decode"] = (_I, [_P, _P, _P, _I, _P, _I64, _I, _P, _P, _P, _I, _P, _P, _P])
 
 _lib = None
+_lab = None
+
+
+def load_lab_library():
+    """The laboratory build, loaded beside the product library (its own kernels and statics; the same HIP runtime)."""
+    global _lab
+    if _lab is None:
+        _lab = load_library(LAB_LIB_PATH)
+    return _lab
 
 
 def load_library(path: str | None = None):

@@ -32,14 +32,16 @@ def _ptr(t):
 class SGACodec:
     def __init__(self, weights: dict, num_filters: int, max_batch: int, max_height: int,
                  max_width: int, device: str | torch.device = "cuda:0", bits_back: bool = False,
-                 precision: str = "default", scale_bound: float = _lib.SCALE_BOUND_NONE):
+                 precision: str = "default", scale_bound: float = _lib.SCALE_BOUND_NONE, lab: bool = False):
         """scale_bound: lower bound on the conditional's sigma in step / run / evaluate.  0 (default) mirrors
         sga.py:130-133 and its siblings, which call `_likelihood` on a tfc layer that is never built (tfc 1.3 bounds
         the scale in build()); 0.11 mirrors a built layer, mbt2018.py:77-80 (`base_compress` switches to it for the
         call).  include/sga_hip.h, SGA_SCALE_BOUND_*."""
         if not torch.cuda.is_available():
             raise RuntimeError("SGACodec needs a ROCm GPU (gfx950); there is no CPU fallback")
-        self.lib = _lib.load_library()
+        # lab=True: the laboratory build of the library (libsga_hip_lab.so), which honours the ablation switches of
+        # DESIGN_EXPERIMENTS.md; tests compare the shipped kernels with the launches they replace through it
+        self.lib = _lib.load_lab_library() if lab else _lib.load_library()
         self.device = torch.device(device)
         self.C = int(num_filters)
         self.bits_back = bool(bits_back)
@@ -278,21 +280,16 @@ class SGACodec:
 
     def base_compress(self, x, medians=None, scale_bound: float = _lib.SCALE_BOUND_BUILT):
         """mbt2018.py compress, estimated-rate path (cfg 1).  mbt2018.py:80 CALLS the conditional layer, so tfc builds
-        it and bounds sigma below by scale_table[0] = 0.11: the handle's bound is switched to `scale_bound` for the
-        call and restored afterwards."""
+        it and bounds sigma below by scale_table[0] = 0.11: `scale_bound` is an argument of this call only
+        (sga_base_compress_bound): the handle's own bound and its cached step graphs are left alone."""
         x = self._t(x)
         B, H, W, ys, zs = self._shapes(x)
         med = self._t(medians, (self.C,)) if medians is not None else None
         y_hat, z_hat, met = self._empty(*ys), self._empty(*zs), self._empty(B, 7)
-        keep = self.scale_bound
-        self.set_scale_bound(scale_bound)
-        try:
-            s = self._enter()
-            self._chk(self.lib.sga_base_compress(self.handle, _ptr(x), B, H, W, _ptr(med), _ptr(y_hat),
-                                                 _ptr(z_hat), _ptr(met), s), "sga_base_compress")
-            self._exit()
-        finally:
-            self.set_scale_bound(keep)
+        s = self._enter()
+        self._chk(self.lib.sga_base_compress_bound(self.handle, _ptr(x), B, H, W, _ptr(med), float(scale_bound), _ptr(y_hat),
+                                                   _ptr(z_hat), _ptr(met), s), "sga_base_compress_bound")
+        self._exit()
         return y_hat, z_hat, met
 
     # ---- bb_sga.py (cfg 5): SGA + bits-back; needs bits_back=True ---------------------------------
@@ -401,7 +398,9 @@ class SGACodec:
             dm = None
             if device_tables:
                 dm = (lambda v: self.factorized_likelihood(v)[0].cpu().numpy(),
-                      lambda y, mu, sr: self.gaussian_likelihood(y, mu, sr)[0].cpu().numpy())
+                      # a FIXED bound (the scale table's own minimum), whatever the handle's mutable sigma bound is at the
+                      # moment: an encoder and a decoder must build identical tables
+                      lambda y, mu, sr: self.gaussian_likelihood(y, mu, sr, scale_bound=_lib.SCALE_BOUND_BUILT)[0].cpu().numpy())
             self._ec = EntropyCoder(weights if weights is not None else self._weights_for_ec, device_models=dm)
             self._ec_dev = device_tables
         return self._ec
@@ -633,13 +632,15 @@ class SGACodec:
         self._exit()
         return p, dp
 
-    def gaussian_likelihood(self, y, mu, sigma_raw):
+    def gaussian_likelihood(self, y, mu, sigma_raw, scale_bound=None):
+        """scale_bound=None: the handle's current bound; a number: that bound for this call only."""
         y, mu, sr = self._t(y), self._t(mu), self._t(sigma_raw)
         outs = [torch.empty_like(y) for _ in range(4)]
         s = self._enter()
-        self._chk(self.lib.sga_op_gaussian_likelihood(self.handle, _ptr(y), _ptr(mu), _ptr(sr),
-                                                      y.numel(), *[_ptr(o) for o in outs], s),
-                  "sga_op_gaussian_likelihood")
+        sb = self.scale_bound if scale_bound is None else float(scale_bound)
+        self._chk(self.lib.sga_op_gaussian_likelihood_bound(self.handle, _ptr(y), _ptr(mu), _ptr(sr),
+                                                            y.numel(), sb, *[_ptr(o) for o in outs], s),
+                  "sga_op_gaussian_likelihood_bound")
         self._exit()
         return tuple(outs)
 

@@ -98,7 +98,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 constexpr int post_rows(int BM, int BN) { return BM < 128 ? BM : (BN <= 192 ? 128 : 64); }
 constexpr int post_qbufs(int BM) { return BM < 128 ? 1 : 2; }
 template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3, int POST = 0>
-__global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || WM * WN >= 8)) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int RPP = NT / 8;                 // tile rows covered by one pass of the loaders
@@ -119,10 +119,10 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
   constexpr int LDS_FLOATS0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   constexpr int LDS_FLOATS = LDS_FLOATS0 > POST_FLOATS ? LDS_FLOATS0 : POST_FLOATS;
   static_assert(!POST || (((BM == 256 && (BN == 192 || BN == 256) && NT == 512 && TM == 2 && HASPOST) ||
-                           (BM == 64 && BN == 192 && NT == 256 && TM == 1 && (POST == 1 || POST == 3))) && !X3 && !SMALLC && PRO == PRO_NONE),
+                           (BM == 64 && BN == 192 && NT == 256 && TM == 1 && (POST == 1 || POST == 3))) && !SMALLC && PRO == PRO_NONE),
                 "post-phase instance");
-  constexpr int PBX = X3 ? (BN * 12) / NT : 1;     // 16-byte pieces of the 3-plane weight tile per thread
-  static_assert(!X3 || (BN * 12) % NT == 0, "x3 loader mismatch");
+  constexpr int PBX = X3 ? (BN * 12 + NT - 1) / NT : 1;     // 16-byte pieces of the 3-plane weight tile per thread
+  constexpr bool PBX_TAIL = X3 && (BN * 12) % NT != 0;       // ... the last round covers part of the threads (8 waves x BN = 192)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + BM * LDK;
@@ -290,7 +290,8 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
       for (int k = 0; k < PBX; ++k) {
         const int f = tid + NT * k;
         const int nl = f / 12, piece = f - nl * 12;
-        rbx[k] = *reinterpret_cast<const u32x4*>(wb + (size_t)nl * (a.Cin / BK) * 96 + piece * 8);
+        if (!PBX_TAIL || k + 1 < PBX || f < BN * 12)
+          rbx[k] = *reinterpret_cast<const u32x4*>(wb + (size_t)nl * (a.Cin / BK) * 96 + piece * 8);
       }
     } else {
 #pragma unroll
@@ -494,7 +495,8 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && TN >= 4) ? 1 : 2) void conv_mf
         const int f = tid + NT * k;
         const int nl = f / 12, piece = f - nl * 12;
         const int plane = piece >> 2, j = piece & 3;
-        *reinterpret_cast<u32x4*>(smem_b + B3_BASE + plane * B_PLANE + nl * X3_PITCH + j * 16) = rbx[k];
+        if (!PBX_TAIL || k + 1 < PBX || f < BN * 12)
+          *reinterpret_cast<u32x4*>(smem_b + B3_BASE + plane * B_PLANE + nl * X3_PITCH + j * 16) = rbx[k];
       }
     } else {
 #pragma unroll
@@ -1008,27 +1010,37 @@ int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream) {
 
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
   const int bn = a.Npad / a.ntiles_n;
-  if ((a.bm == 64 || a.bm == 256) && !a.zeros) return (int)hipErrorInvalidValue;   // LDS-DMA instances read the zero page
+  if ((a.bm == 64 || a.bm == 256) && !a.x3 && !a.zeros) return (int)hipErrorInvalidValue;   // LDS-DMA instances read the zero page
   switch (bn) {
     case 192:
       if (a.bm == 64) {
-        if (a.smallc || a.pro != PRO_NONE || a.x3) return (int)hipErrorInvalidValue;
+        if (a.smallc || a.pro != PRO_NONE) return (int)hipErrorInvalidValue;
         if (a.post) {
           if (a.ksplit > 1 || a.epi != EPI_BIAS || a.Cout != 192 || a.out_coff != 0 || a.out_cs != 192 || a.post_p)
             return (int)hipErrorInvalidValue;
+          if (a.x3) return launch_inst<1, 3, 2, 2, PRO_NONE, false, true, 1>(a, stream);
           return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 1>(a, stream);
         }
+        if (a.x3) return launch_inst<1, 3, 2, 2, PRO_NONE, false, true>(a, stream);
+#ifdef SGA_EXPERIMENTS
         if (a.lowfoot) return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 3>(a, stream);
+#endif
         return launch_inst<1, 3, 2, 2, PRO_NONE, false>(a, stream);
       }
       if (a.bm == 256) {
-        if (a.smallc || a.pro != PRO_NONE || a.x3) return (int)hipErrorInvalidValue;
+        if (a.smallc || a.pro != PRO_NONE) return (int)hipErrorInvalidValue;
         if (a.post) {
           if (a.ksplit > 1 || a.epi != EPI_BIAS || a.Cout != 192 || a.out_coff != 0 || a.out_cs != 192)
             return (int)hipErrorInvalidValue;
+          if (a.x3) return a.post_p ? (int)hipErrorInvalidValue : launch_inst<2, 3, 4, 2, PRO_NONE, false, true, 1>(a, stream);
+#ifdef SGA_EXPERIMENTS
           if (a.post_p) return launch_inst<2, 3, 4, 2, PRO_NONE, false, false, 2>(a, stream);
+#else
+          if (a.post_p) return (int)hipErrorInvalidValue;
+#endif
           return launch_inst<2, 3, 4, 2, PRO_NONE, false, false, 1>(a, stream);
         }
+        if (a.x3) return launch_inst<2, 3, 4, 2, PRO_NONE, false, true>(a, stream);
         return launch_inst<2, 3, 4, 2, PRO_NONE, false>(a, stream);
       }
       return launch_pro<2, 3, 2, 2>(a, stream);

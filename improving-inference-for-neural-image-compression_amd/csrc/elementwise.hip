@@ -1017,7 +1017,7 @@ int launch_step_boundary(float* py, const float* gay, const float* gby, float* j
   // counter 1632 workgroups serialised to 25 us); fewer than ~400 leave the relaxation's long dependent chains (Philox,
   // log, atanh, exp) too little parallelism
   int gy = grid_for(ny), gz = grid_for(nz);
-  static const int cap = getenv("SGA_BOUNDARY_CAP") ? atoi(getenv("SGA_BOUNDARY_CAP")) : 1024;
+  static const int cap = LAB_ENV("SGA_BOUNDARY_CAP") ? atoi(LAB_ENV("SGA_BOUNDARY_CAP")) : 1024;
   if (gy + gz > cap) {
     gz = gz > cap / 8 ? cap / 8 : gz;
     gy = gy > cap - gz ? cap - gz : gy;

@@ -372,7 +372,7 @@ void pick_shape(int C, long long M, bool conv3, int& wm, int& wn) {
   const int nc = C / 32;
   if (nc == 8) { wm = 1; wn = 4; } else { wm = 2; wn = 2; }
   const long long tiles = (M + wm * 32 - 1) / (wm * 32);
-  static const int force = [] { const char* e = getenv("SGA_GDN_SHAPE"); return e ? atoi(e) : 0; }();   // experiments
+  static const int force = [] { const char* e = LAB_ENV("SGA_GDN_SHAPE"); return e ? atoi(e) : 0; }();   // experiments
   if (((tiles < 256 && force != 2) || force == 1) && !conv3) { wm = 1; wn = nc; }
 }
 

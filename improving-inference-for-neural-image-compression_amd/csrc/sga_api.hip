@@ -131,8 +131,11 @@ struct sga_handle {
   bool fork_auto = true;           // the fork point is chosen per geometry by timing the candidates (off when SGA_FORK_AT is set)
   bool graph_tuned = false;        // the cached step graph was built with a timed fork point
   bool bb_graph_tuned = false;     // ... and the bits-back stage-1 graph
-  bool x3_fork = false;            // bf16x3 mode with the hyper branch on the second stream (SGA_X3_FORK=1; see DESIGN_EXPERIMENTS.md A.8)
-  bool drop_destroy = false;       // drop_graph(): destroy a dropped executable graph at once (SGA_GRAPH_DROP=destroy) or retire it
+  bool x3_variants = true;         // bf16x3 mode: 64- / 256-row tiles and the IGDN post-phase as in f32 mode (SGA_X3_VARIANTS=0: 128-row only)
+  bool x3_fork = true;             // bf16x3 mode with the hyper branch on the second stream (round 4: on again, never forked at the
+                                   //   graph's root -- synth_branch tick(); SGA_X3_FORK=0: single-stream as in rounds 2-3)
+  bool drop_destroy = true;        // drop_graph(): destroy a dropped executable graph at once (default) or keep it until sga_destroy
+                                   //   (SGA_GRAPH_DROP=retire: the round-3 policy)
   std::vector<hipGraphExec_t> retired_graphs;   // candidate graphs that lost the timing: destroyed with the handle (experiment:
                                    // destroying them while their sibling is in use crashed the process in the full test suite)
   int tuned_B = 0, tuned_H = 0, tuned_W = 0;   // geometry the last timed choice (tuned_name) was made for: graphs of that
@@ -191,6 +194,7 @@ struct sga_handle {
 
 extern int g_deconv3_prio;
 
+#ifdef SGA_EXPERIMENTS
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
@@ -203,6 +207,7 @@ static void sga_segv_handler(int sig) {      // debugging aid (SGA_DEBUG_SEGV=1)
   signal(sig, SIG_DFL);
   raise(sig);
 }
+#endif
 
 namespace {
 
@@ -264,7 +269,7 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   if (a.out_coff != 0 || a.out_cs != a.Cout || (a.Cout & 3)) return 1;
   const int tiles = a.tiles_per_phase * a.ntiles_n;
   const int blocks = a.nphase * tiles;
-  static const int main_target = getenv("SGA_MAIN_TARGET") ? atoi(getenv("SGA_MAIN_TARGET")) : 512;   // experiments
+  static const int main_target = LAB_ENV("SGA_MAIN_TARGET") ? atoi(LAB_ENV("SGA_MAIN_TARGET")) : 512;   // experiments
   int target = a.bm == 256 ? 256 : main_target;      // ~512 workgroups of (nearly) equal K length (tuned at cfg 2); 256-row: one per CU
   if (h->in_hyper && h->side_target > 0) target = h->side_target;   // hyper branch (whichever stream it runs on: the
                                                                      // split decides the summation order, i.e. result bits)
@@ -337,7 +342,8 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   // between (Kodak / Tecnick shapes) the height whose grid quantises best into rounds of resident
   // workgroups wins (grid_efficiency): e.g. 576 128-row tiles = 1.1 rounds, as 1152 64-row tiles 1.5.
   a.bm = 128;
-  const bool variants = !h->x3 && !a.smallc && a.pro == PRO_NONE && a.Npad / a.ntiles_n == 192 &&
+  // (bf16x3 mode: the same tile heights on the register-staged X3 instances, unless SGA_X3_VARIANTS=0)
+  const bool variants = (!h->x3 || h->x3_variants) && !a.smallc && a.pro == PRO_NONE && a.Npad / a.ntiles_n == 192 &&
                         (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RELU_MASK);
   if (variants) {
     const long long rows = (long long)a.B * a.Hg * a.Wg;
@@ -350,7 +356,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     // workgroups per CU (in-kernel probe, profiles/r02_clock_probe.txt: 5.70 us per 256 x 192 x 32 step) --
     // more than the second slab costs: gs2.bwd at cfg 2 467 -> 448 us, iteration 1834 -> 1823 us.
     // SGA_BM256_MIN (experiment): also single-phase launches of 32 / 64 such tiles, split 8 / 4 ways
-    static const int bm256_min = getenv("SGA_BM256_MIN") ? atoi(getenv("SGA_BM256_MIN")) : 128;
+    static const int bm256_min = LAB_ENV("SGA_BM256_MIN") ? atoi(LAB_ENV("SGA_BM256_MIN")) : 128;
     const bool one_per_cu = h->bm256_split && a.nphase == 1 &&
                             (n256 == 128 || n256 == 256 || (n256 >= bm256_min && (n256 == 32 || n256 == 64)));
     if (one_per_cu) bm = 256;
@@ -407,13 +413,13 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     if (ccs == hipStreamCaptureStatusActive) a.clk = h->clk_probe + h->clk_slots.size() * (size_t)(6 * 16384);
   }
 #endif
-  { static const int rb = getenv("SGA_REDUCE_BATCH") ? atoi(getenv("SGA_REDUCE_BATCH")) : 2;
+  { static const int rb = LAB_ENV("SGA_REDUCE_BATCH") ? atoi(LAB_ENV("SGA_REDUCE_BATCH")) : 2;
     a.reduce_batch = rb == 2 ? 1 : (rb == 1 ? (h->cur_part == &h->part) : 0); }
   {
     const long long blocks = (long long)a.nphase * a.tiles_per_phase * a.ntiles_n;
     const int per_cu = a.bm == 64 ? 3 : (a.bm == 128 ? 2 : 1);
     a.pair_phases = (a.nphase == 4 && a.ksplit <= 1 && blocks > 256 && blocks <= 256LL * per_cu) ? 1 : 0;
-    static const int xr = getenv("SGA_XCD_REMAP") ? atoi(getenv("SGA_XCD_REMAP")) : 1;
+    static const int xr = LAB_ENV("SGA_XCD_REMAP") ? atoi(LAB_ENV("SGA_XCD_REMAP")) : 1;
     a.xcd_remap = (xr && a.ksplit <= 1 && a.ntiles_n == 1 && a.tiles_per_phase % 8 == 0 && blocks >= 256) ? 1 : 0;
   }
   if (defer && a.epi != EPI_BIAS) return SGA_ERR_BAD_ARG;   // the consumer applies "+ bias" only
@@ -421,7 +427,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     // 256-row tiles (8 waves, C = 192 / 256) and the 64-row 4-wave instance at C = 192 (gs1.fwd + igdn1.fwd 170 -> 156 us
     // alone at cfg 2; inside the iteration it pays only with the later fork point of the hyper branch: the joint sweep of
     // DESIGN_EXPERIMENTS.md A.7; SGA_FUSED_POST64=0 turns it off)
-    const bool post_tile = a.bm == 256 || (a.bm == 64 && a.Cout == 192 && h->fused_post64 && !h->x3);
+    const bool post_tile = a.bm == 256 || (a.bm == 64 && a.Cout == 192 && h->fused_post64);
     post->fused = h->fused_post && post_tile && a.ksplit <= 1 && (a.Cout == 192 || a.Cout == 256) && a.Npad == a.Cout &&
                   a.epi == EPI_BIAS && a.out_coff == 0 && a.out_cs == a.Cout && post->s_out && post->v_out;
     if (post->fused) {
@@ -592,8 +598,8 @@ int upload_packed(sga_handle* h, PackedConv& pc, const std::vector<float>& host,
 // hs2.bwd 86 -> 62 us; inside the iteration only together with the other "faster alone" variants and a later fork point
 // (joint sweep, DESIGN_EXPERIMENTS.md A.7).  SGA_BN96_AS_192=0 restores the BN = 96 instance.
 bool bn96_as_192(const sga_handle* h) {
-  const char* e = getenv("SGA_BN96_AS_192");
-  return !h->x3 && !(e && e[0] == '0');
+  const char* e = LAB_ENV("SGA_BN96_AS_192");
+  return (!h->x3 || h->x3_variants) && !(e && e[0] == '0');
 }
 
 // GEMM with N = co, K = ci:  w[t][co][ci] = K[t][ci][co]   (forward of any conv)
@@ -1058,7 +1064,11 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   // call before every main-chain launch.  The hyper branch is forked at launch number `fork_at` (SGA_FORK_AT, experiments)
   // or, when the handle names one (fork_name: chosen per geometry by sga_run_steps), right before that launch
   auto tick = [&](const char* name = nullptr) -> int {
-    const bool here = h->fork_name ? (name && strcmp(name, h->fork_name) == 0) : launches >= fork_at;
+    // Never before the FIRST launch: the branch's first kernel would then be a second root node of the captured graph, with
+    // no predecessor inside it.  Measured (round 4, scripts/x3_fork_race.py): bf16x3 mode forked at the root gave 3 different
+    // outcomes in 20 identical 300-iteration graph replays (all diverging at iteration 33), forked after the first launch 20
+    // of 20 identical; eager launches, and the f32 kernels in either position, 20 of 20 (DESIGN_EXPERIMENTS.md A.8).
+    const bool here = (h->fork_name ? (name && strcmp(name, h->fork_name) == 0) : launches >= fork_at) && launches >= 1;
     if (side && !side_started && here) { side_started = true; SGACHK((*side)()); }
     // second fork point (captured graph only): the branch's BACKWARD half may not start before this launch
     if (side2 && !side2_started && name && h->fork2_name && strcmp(name, h->fork2_name) == 0) { side2_started = true; SGACHK((*side2)()); }
@@ -1275,12 +1285,21 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
 }
 
 // Disposal of an executable graph that is dropped in mid-life (a losing fork-point candidate, a geometry change, a changed
-// sigma bound, the stamped graph of sga_profile_graph_*).  Policy (sga_handle::drop_destroy, SGA_GRAPH_DROP=destroy|retire):
-// destroy it now -- the caller has synchronised the stream(s) its replays ran on -- or keep it until sga_destroy.
-void drop_graph(sga_handle* h, hipGraphExec_t& ex) {
+// sigma bound, the stamped graph of sga_profile_graph_*): destroyed after BOTH streams its replays ran on have drained
+// (`st`: the launching stream; the handle's second stream carries the hyper branch of every replay).  Round 3 kept dropped
+// graphs until sga_destroy because three full-suite runs had crashed shortly after a mid-life hipGraphExecDestroy; round 4
+// could not reproduce that with the synchronisation in place -- full GPU suite under MALLOC_PERTURB_ with this policy, a
+// stand-alone HIP program with the same life cycle incl. destruction with replays in flight (scripts/graph_repro.hip): all
+// clean -- see DESIGN_EXPERIMENTS.md A.8.  SGA_GRAPH_DROP=retire restores the old policy.
+void drop_graph(sga_handle* h, hipGraphExec_t& ex, hipStream_t st = nullptr) {
   if (!ex) return;
-  if (h->drop_destroy) (void)hipGraphExecDestroy(ex);
-  else h->retired_graphs.push_back(ex);
+  if (h->drop_destroy) {
+    if (st) (void)hipStreamSynchronize(st);
+    if (h->sB) (void)hipStreamSynchronize(h->sB);
+    (void)hipGraphExecDestroy(ex);
+  } else {
+    h->retired_graphs.push_back(ex);
+  }
   ex = nullptr;
 }
 
@@ -1311,8 +1330,8 @@ int timed_fork_choice(sga_handle* h, hipStream_t st, int B, int H, int W, Cap&& 
     ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
          hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
     if (!ok) {      // a failed launch leaves the run in an unknown state: report it
-      drop_graph(h, ex);
-      drop_graph(h, best);
+      drop_graph(h, ex, st);
+      drop_graph(h, best, st);
       (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
       h->fork_name = nullptr;
       HIPCHK(h, hipErrorUnknown);
@@ -1324,10 +1343,10 @@ int timed_fork_choice(sga_handle* h, hipStream_t st, int B, int H, int W, Cap&& 
     // the losing candidates are kept until the handle goes (two small executable graphs per tuned geometry): see
     // sga_handle::retired_graphs
     if (!best || ms < best_ms) {
-      drop_graph(h, best);
+      drop_graph(h, best, st);
       best = ex; best_ms = ms; best_name = cands[c];
     } else {
-      drop_graph(h, ex);
+      drop_graph(h, ex, st);
     }
   }
   (void)hipEventDestroy(e0);
@@ -1369,7 +1388,9 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   if (!(cfg->scale_bound >= 0.f) || !(cfg->scale_bound < 1e30f)) return SGA_ERR_BAD_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return SGA_ERR_NO_DEVICE;
-  if (getenv("SGA_DEBUG_SEGV")) { signal(SIGSEGV, sga_segv_handler); signal(SIGBUS, sga_segv_handler); }
+#ifdef SGA_EXPERIMENTS
+  if (LAB_ENV("SGA_DEBUG_SEGV")) { signal(SIGSEGV, sga_segv_handler); signal(SIGBUS, sga_segv_handler); }
+#endif
   sga_handle* h = new (std::nothrow) sga_handle();
   if (!h) return SGA_ERR_NOMEM;
   h->cfg = *cfg;
@@ -1381,6 +1402,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     const char* pe = getenv("SGA_PRECISION");
     h->x3 = cfg->precision == SGA_PRECISION_BF16X3 ||
             (cfg->precision == SGA_PRECISION_DEFAULT && pe && strcmp(pe, "bf16x3") == 0);
+    pe = getenv("SGA_X3_VARIANTS");      // read here: the weight packing below depends on it (bn96_as_192)
+    h->x3_variants = !(pe && pe[0] == '0');
   }
   int st = SGA_OK;
   auto fail = [&](int code) { free_all(h); delete h; return code; };
@@ -1439,12 +1462,12 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
       // to the hyper branch): the halo kernel stays the default, SGA_GS3_GEMM=1 selects this path.
       // Round 3: ON by default -- together with the other faster-alone variants and the later fork point of the hyper branch
       // the iteration is 30 us shorter (joint sweep, DESIGN_EXPERIMENTS.md A.7); SGA_GS3_GEMM=0 selects the halo kernel.
-      const char* eg = getenv("SGA_GS3_GEMM");
+      const char* eg = LAB_ENV("SGA_GS3_GEMM");
       h->gs3_gemm = !(eg && eg[0] == '0');
-      eg = getenv("SGA_POST_P");
+      eg = LAB_ENV("SGA_POST_P");
       h->post_p = eg && eg[0] == '1';
     }
-    const char* e3 = getenv("SGA_GS3_GENERIC");
+    const char* e3 = LAB_ENV("SGA_GS3_GENERIC");
     h->gs3_generic = e3 && e3[0] == '1';
   }
   TRY(pack_smallc(h, h->gs_b[3], w->gs_kernel[3], C, true));
@@ -1546,7 +1569,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     if (hipMemset(p, 0, 256) != hipSuccess) return fail(SGA_ERR_HIP);
     h->zeros = (float*)p;
 #ifdef SGA_CLOCK_PROBE
-    if (const char* e = getenv("SGA_CLOCK_PROBE")) {
+    if (const char* e = LAB_ENV("SGA_CLOCK_PROBE")) {
       h->clk_mode = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0);
       if (h->clk_mode) {
         void* q = nullptr;
@@ -1586,13 +1609,13 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     // The side stream has normal priority (a high-priority one measured the same throughput).
     int prio = 0;
     (void)lo; (void)hi;
-    if (const char* pr = getenv("SGA_SIDE_PRIORITY")) prio = atoi(pr);   // experiments only
+    if (const char* pr = LAB_ENV("SGA_SIDE_PRIORITY")) prio = atoi(pr);   // experiments only
     const unsigned evflags = hipEventDisableTiming;
     // Experiment: SGA_SIDE_CU_MASK=<hex words, lowest first, comma separated> confines the hyper branch's
     // stream to the CUs whose bits are set (hipExtStreamCreateWithCUMask).  A mask belongs to a stream, and kernel
     // nodes of a replayed hipGraph do not inherit it, so this only acts on eager launches (SGA_NO_GRAPH=1).
     bool masked = false;
-    if (const char* cm = getenv("SGA_SIDE_CU_MASK")) {
+    if (const char* cm = LAB_ENV("SGA_SIDE_CU_MASK")) {
       std::vector<uint32_t> words;
       for (const char* q = cm; *q;) {
         char* end = nullptr;
@@ -1606,7 +1629,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     h->side_masked = masked;
     // Experiment: SGA_HYBRID=1 runs the same hybrid replay with an unmasked side stream of priority SGA_SIDE_PRIORITY
     // (hardware-queue priorities act on eager streams; graph nodes ignore them)
-    if (const char* hy = getenv("SGA_HYBRID")) h->side_hybrid = hy[0] == '1';
+    if (const char* hy = LAB_ENV("SGA_HYBRID")) h->side_hybrid = hy[0] == '1';
     if ((!masked && hipStreamCreateWithPriority(&h->sB, hipStreamNonBlocking, prio) != hipSuccess) ||
         hipEventCreateWithFlags(&h->ev_fork, evflags) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, evflags) != hipSuccess ||
@@ -1618,7 +1641,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   env = getenv("SGA_PRECISION");
   h->x3 = cfg->precision == SGA_PRECISION_BF16X3 ||
           (cfg->precision == SGA_PRECISION_DEFAULT && env && strcmp(env, "bf16x3") == 0);
-  env = getenv("SGA_DEBUG_DUMP");
+  env = LAB_ENV("SGA_DEBUG_DUMP");
   if (env && env[0]) {
     h->dump_path = env;
     void* p = nullptr;
@@ -1626,51 +1649,51 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     h->dump = (unsigned long long*)p;
   }
   env = getenv("SGA_X3_FORK");
-  h->x3_fork = env && env[0] == '1';
+  h->x3_fork = !(env && env[0] == '0');
   env = getenv("SGA_GRAPH_DROP");
-  if (env) h->drop_destroy = strcmp(env, "destroy") == 0;
-  env = getenv("SGA_SPLIT256");
+  if (env) h->drop_destroy = strcmp(env, "retire") != 0;
+  env = LAB_ENV("SGA_SPLIT256");
   h->split256 = !(env && env[0] == '0');
-  env = getenv("SGA_BM256");
+  env = LAB_ENV("SGA_BM256");
   h->bm256 = !(env && env[0] == '0');
-  env = getenv("SGA_BM256_SPLIT");
+  env = LAB_ENV("SGA_BM256_SPLIT");
   h->bm256_split = h->bm256 && !(env && env[0] == '0');
-  env = getenv("SGA_BM64_MAX");
+  env = LAB_ENV("SGA_BM64_MAX");
   if (env) h->bm64_max = atoi(env);
-  env = getenv("SGA_FORK_AT");
+  env = LAB_ENV("SGA_FORK_AT");
   if (env) { h->fork_at = atoi(env); h->fork_auto = false; }
   env = getenv("SGA_FORK_NAME");       // experiments: pin the named fork point(s) ("start" = at the first launch)
   if (env) { h->fork_auto = false; h->fork_name = strcmp(env, "start") == 0 ? nullptr : strdup(env); }
-  env = getenv("SGA_FORK2_NAME");
+  env = LAB_ENV("SGA_FORK2_NAME");
   if (env) { h->fork_auto = false; h->fork2_name = strcmp(env, "none") == 0 ? nullptr : strdup(env); }
-  env = getenv("SGA_SIDE_LAST");
+  env = LAB_ENV("SGA_SIDE_LAST");
   if (env) h->side_last = env[0] == '1';
-  env = getenv("SGA_SIDE_TARGET");
+  env = LAB_ENV("SGA_SIDE_TARGET");
   if (env) h->side_target = atoi(env);
-  env = getenv("SGA_FUSED_GDN");
+  env = LAB_ENV("SGA_FUSED_GDN");
   h->fused_gdn = !(env && env[0] == '0');
   // gdn_fused.hip has instances for C / 32 in {2, 4, 6, 8}; wider models (num_filters = 320, 384, ...) take the generic
   // gather-GEMM GDN with an ordinary split-K reduce (conv_mfma.hip tiles any channel count)
   if (C / 32 != 2 && C / 32 != 4 && C / 32 != 6 && C / 32 != 8) h->fused_gdn = false;
-  env = getenv("SGA_KEEP_U");
+  env = LAB_ENV("SGA_KEEP_U");
   h->keep_u = env && env[0] == '1';
-  env = getenv("SGA_FORK_DELAY_US");
+  env = LAB_ENV("SGA_FORK_DELAY_US");
   if (env) h->fork_delay_us = atoi(env);
-  env = getenv("SGA_SIDE_LOWFOOT");
+  env = LAB_ENV("SGA_SIDE_LOWFOOT");
   h->side_lowfoot = env && env[0] == '1';
-  env = getenv("SGA_MAIN_WAVE_PRIO");
+  env = LAB_ENV("SGA_MAIN_WAVE_PRIO");
   if (env) { h->main_wave_prio = atoi(env); g_deconv3_prio = h->main_wave_prio; }
-  env = getenv("SGA_SIDE_WAVE_PRIO");
+  env = LAB_ENV("SGA_SIDE_WAVE_PRIO");
   if (env) h->side_wave_prio = atoi(env);
-  env = getenv("SGA_FUSED_POST64");
+  env = LAB_ENV("SGA_FUSED_POST64");
   h->fused_post64 = !(env && env[0] == '0');
-  env = getenv("SGA_FUSED_POST");
+  env = LAB_ENV("SGA_FUSED_POST");
   h->fused_post = !(env && env[0] == '0');
-  env = getenv("SGA_PLAN_TILES");
+  env = LAB_ENV("SGA_PLAN_TILES");
   h->plan_tiles = !(env && env[0] == '0');
-  env = getenv("SGA_FUSED_BOUNDARY");
+  env = LAB_ENV("SGA_FUSED_BOUNDARY");
   h->fused_boundary = !(env && env[0] == '0');
-  env = getenv("SGA_FUSED_MSE");
+  env = LAB_ENV("SGA_FUSED_MSE");
   h->fused_mse = !(env && env[0] == '0');
   env = getenv("SGA_NO_SPLITK");
   h->no_splitk = env && env[0] == '1';
@@ -1689,7 +1712,7 @@ int sga_destroy(sga_handle* h) {
     for (size_t s = 0; s < h->clk_slots.size(); ++s) {
       if (hipMemcpy(t.data(), h->clk_probe + s * (size_t)(6 * 16384), t.size() * sizeof(t[0]), hipMemcpyDeviceToHost) != hipSuccess) break;
       if (strncmp(h->clk_slots[s].name, "gdn:", 4) == 0) {      // raw [grid][8] u64 wall-clock stamps (gdn_fused.hip)
-        if (const char* dir = getenv("SGA_CLOCK_PROBE_DUMP")) {
+        if (const char* dir = LAB_ENV("SGA_CLOCK_PROBE_DUMP")) {
           char fn[512];
           snprintf(fn, sizeof(fn), "%s/gdn_slot_%02zu.bin", dir, s);
           if (FILE* f = fopen(fn, "wb")) { fwrite(t.data(), sizeof(t[0]), 8 * (size_t)h->clk_slots[s].grid, f); fclose(f); }
@@ -1703,7 +1726,7 @@ int sga_destroy(sga_handle* h) {
         wmin = std::min(wmin, (double)t[6 * i + 1]); wmax = std::max(wmax, (double)t[6 * i + 1]);
       }
       const int g = h->clk_slots[s].grid;
-      if (const char* dir = getenv("SGA_CLOCK_PROBE_DUMP")) {      // raw [grid][6] u64: K-loop cycles, K-loop wall ticks, hw_id | xcc_id << 32, wall at K-loop start, at entry, at exit
+      if (const char* dir = LAB_ENV("SGA_CLOCK_PROBE_DUMP")) {      // raw [grid][6] u64: K-loop cycles, K-loop wall ticks, hw_id | xcc_id << 32, wall at K-loop start, at entry, at exit
         char fn[512];
         snprintf(fn, sizeof(fn), "%s/clk_slot_%02zu.bin", dir, s);
         if (FILE* f = fopen(fn, "wb")) { fwrite(t.data(), sizeof(t[0]), 6 * (size_t)g, f); fclose(f); }
@@ -1931,7 +1954,7 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
     if (h->graph_main) {
       HIPCHK(h, hipEventRecord(h->ev_fork, st));                  // ev_iter: the relaxed latents of iteration run_it exist
       for (int k = 0; k < n; ++k) {
-        static const bool skip_side = getenv("SGA_SKIP_SIDE") != nullptr;      // timing experiment only: results are wrong
+        static const bool skip_side = LAB_ENV("SGA_SKIP_SIDE") != nullptr;      // timing experiment only: results are wrong
         HIPCHK(h, hipStreamWaitEvent(h->sB, h->ev_fork, 0));
         h->branch_only = 2;
         const int rs = skip_side ? SGA_OK : rd_forward_backward(h, g, h->xin.p, true, h->sB);
@@ -1973,14 +1996,14 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
     // 1.59 against 1.52 ms).  So a call with enough iterations left times the three candidates once per geometry -- on
     // the run's own iterations: 8 replays of each candidate graph, which count -- and keeps the fastest graph
     // (DESIGN.md 3.7).  SGA_FORK_AT=<n> pins the point instead.
-    const bool tune = h->fork_auto && fb && h->overlap && !h->x3 && !h->gprof && n >= 100;
+    const bool tune = h->fork_auto && fb && h->overlap && (!h->x3 || h->x3_fork) && !h->gprof && n >= 100;
     const bool stale = !h->graph_exec || h->graph_B != B || h->graph_H != H || h->graph_W != W || h->graph_relax != h->relax;
     if (stale || (tune && !h->graph_tuned)) {
       if (h->graph_exec) {
         // replays of the old graph may still be queued (a short run followed at once by a long one): let them finish
         // before the executable graph is destroyed
         HIPCHK(h, hipStreamSynchronize(st));
-        drop_graph(h, h->graph_exec);
+        drop_graph(h, h->graph_exec, st);
       }
       h->graph_tuned = false;
       if (!tune) {
@@ -2076,6 +2099,18 @@ int sga_quantize_centered(sga_handle* h, const float* y, const float* z, int B, 
   HIPCHK(h, launch_round_centered(y, h->ms.p, B, g.yh, g.yw, g.hsh, g.hsw, C, y_hat, st));
   HIPCHK(h, launch_round_median(z, medians, nz, C, z_hat, st));
   return SGA_OK;
+}
+
+int sga_base_compress_bound(sga_handle* h, const float* x, int B, int H, int W, const float* medians, float scale_bound,
+                            float* y_hat, float* z_hat, float* metrics, void* stream) {
+  if (!h || !(scale_bound >= 0.f) || !(scale_bound < 1e30f)) return SGA_ERR_BAD_ARG;
+  // the call launches eagerly (no captured graph is involved), so the bound is an argument of THIS call's k_gaussian launch
+  // only: nothing is synchronised, no cached step graph is dropped
+  const float keep = h->scale_bound;
+  h->scale_bound = scale_bound;
+  const int rc = sga_base_compress(h, x, B, H, W, medians, y_hat, z_hat, metrics, stream);
+  h->scale_bound = keep;
+  return rc;
 }
 
 int sga_base_compress(sga_handle* h, const float* x, int B, int H, int W, const float* medians,
@@ -2204,12 +2239,19 @@ int sga_op_factorized_likelihood(sga_handle* h, const float* v, int64_t n_pix, f
   return SGA_OK;
 }
 
+int sga_op_gaussian_likelihood_bound(sga_handle* h, const float* y, const float* mu, const float* sigma_raw, int64_t n,
+                                     float scale_bound, float* p, float* dp_dy, float* dp_dmu, float* dp_dsraw,
+                                     void* stream) {
+  if (!h || !y || !mu || !sigma_raw || n <= 0 || !(scale_bound >= 0.f) || !(scale_bound < 1e30f)) return SGA_ERR_BAD_ARG;
+  HIPCHK(h, launch_gaussian_op(y, mu, sigma_raw, n, scale_bound, p, dp_dy, dp_dmu, dp_dsraw, (hipStream_t)stream));
+  return SGA_OK;
+}
+
 int sga_op_gaussian_likelihood(sga_handle* h, const float* y, const float* mu,
                                const float* sigma_raw, int64_t n, float* p, float* dp_dy,
                                float* dp_dmu, float* dp_dsraw, void* stream) {
-  if (!h || !y || !mu || !sigma_raw || n <= 0) return SGA_ERR_BAD_ARG;
-  HIPCHK(h, launch_gaussian_op(y, mu, sigma_raw, n, h->scale_bound, p, dp_dy, dp_dmu, dp_dsraw, (hipStream_t)stream));
-  return SGA_OK;
+  if (!h) return SGA_ERR_BAD_ARG;
+  return sga_op_gaussian_likelihood_bound(h, y, mu, sigma_raw, n, h->scale_bound, p, dp_dy, dp_dmu, dp_dsraw, stream);
 }
 
 // The rate half of the graph with fed intermediates (the reference can feed y_tilde / z_tilde and
@@ -2404,7 +2446,7 @@ int bb_iterations(sga_handle* h, int stage, const Geom& g, int n, hipStream_t st
   if (h->use_graph && !h->profiling && n > 0) {
     if (h->bb_graph_B != g.B || h->bb_graph_H != g.H || h->bb_graph_W != g.W) {
       HIPCHK(h, hipStreamSynchronize(st));
-      for (int k = 0; k < 2; ++k) drop_graph(h, h->bb_graph[k]);
+      for (int k = 0; k < 2; ++k) drop_graph(h, h->bb_graph[k], st);
       h->bb_graph_B = g.B; h->bb_graph_H = g.H; h->bb_graph_W = g.W;
       h->bb_graph_tuned = false;
     }
@@ -2423,10 +2465,10 @@ int bb_iterations(sga_handle* h, int stage, const Geom& g, int n, hipStream_t st
     };
     // stage 1 (the full step, bb_sga.py:203-236) forks the hyper branch like the plain SGA step: its fork point is timed the
     // same way (stage 2 is the hyper branch alone: nothing to fork)
-    const bool tune = stage == 0 && h->fork_auto && h->overlap && !h->x3 && n >= 100 && !h->bb_graph_tuned;
+    const bool tune = stage == 0 && h->fork_auto && h->overlap && (!h->x3 || h->x3_fork) && n >= 100 && !h->bb_graph_tuned;
     if (tune && h->bb_graph[0]) {
       HIPCHK(h, hipStreamSynchronize(st));
-      drop_graph(h, h->bb_graph[0]);
+      drop_graph(h, h->bb_graph[0], st);
     }
     if (!h->bb_graph[stage]) {
       if (tune) {

@@ -188,7 +188,7 @@ def run_early_stop(codec, x, lmbda, *, method, its=2000, lr, seed=0, loss_scale=
     return y_hat, z_hat, codec.evaluate(x, y_hat, z_hat), done
 
 
-def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, loss_scale, log_itv=100, log=print):
+def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, loss_scale, log_itv=100, log=print, after=None):
     """sga.py:210-238 with --verbose: at every log point also feed the ROUNDED latents straight into
     the graph (sga.py:219-225) and print both objectives.  The run pauses at the log points
     (sga_run_steps); the rounded latents are evaluated with the relaxation switched off."""
@@ -209,6 +209,8 @@ def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, los
         finally:
             codec.set_relaxation("sga", "exp0")
         t = tr[it].tolist()
+        if after is not None:
+            after.append(r["rd_loss"])                                      # sga.py:231 opt_record['rd_loss_after_rounding']
         log("it=%d, T=%.3f rd_loss=%.4f mse=%.3f bpp=%.4f psnr=%.4f\t after rounding: rd_loss=%.4f, bpp=%.4f psnr=%.4f"
             % (it, T, t[0], t[1], t[2], t[3], r["rd_loss"], r["train_bpp"], float(r["psnr"].mean())))
     if y is None:
@@ -218,10 +220,20 @@ def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, los
 
 def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=700, T_ub=0.5,
                 seed=0, rank=0, world=1, dist=None, verbose=False, log_itv=100, log=print,
-                method="sga", r_its=2000, r_lr=0.003, medians=None, base_scale_bound=None):
+                method="sga", r_its=2000, r_lr=0.003, medians=None, base_scale_bound=None, check_finite=False,
+                opt_record=None, recon=None):
     """The per-batch loop of sga.py:201-253 (method "sga"), bb_sga.py:199-280 ("bb_sga") or the
     one-shot mbt2018.py:159-180 ("mbt2018") over a dataset X [N,H,W,3] float32.
-    Returns dict field -> [N] array (on every rank)."""
+    Returns dict field -> [N] array (on every rank).
+    check_finite: test the logged rows (every `log_itv` iterations and the last one: the points sga.py:216 prints) of every
+      launch's per-iteration trace on the host and raise FloatingPointError naming the first non-finite iteration (SURVEY.md
+      5; the reference lets a NaN run silently for 2000 steps).
+    opt_record: a dict to fill with the optimisation record of this rank's LAST launch -- `its`, `T`, `rd_loss` at the log
+      points, as sga.py:209,234-236 keeps them for the last batch (+ `rd_loss_after_rounding` with --verbose).  rd_loss is
+      the objective of the images in that launch (loss_scale = 1 / len(reference batch)): the reference's value when the
+      launch holds a whole reference batch.
+    recon: a list to receive (image index, x_hat [H,W,3] float32) of this rank's images (sga.py:281-291)."""
+    want_trace = verbose or check_finite or opt_record is not None
     fields = BB_EVAL_FIELDS if method == "bb_sga" else EVAL_FIELDS
     N, H, W, _ = X.shape
     bs = get_eval_batch_size(H * W)
@@ -239,7 +251,7 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
             if method == "bb_sga":
                 _, _, met, tr, _ = codec.bb_run(X[idx], lmbda, its=its, r_its=r_its, lr=lr, r_lr=r_lr,
                                                 annealing_rate=annealing_rate, t0=t0, T_ub=T_ub,
-                                                seed=sd, loss_scale=loss_scale, trace=verbose)
+                                                seed=sd, loss_scale=loss_scale, trace=want_trace)
             elif method == "mbt2018":
                 kw = {} if base_scale_bound is None else dict(scale_bound=base_scale_bound)
                 _, _, met = codec.base_compress(X[idx], medians=medians, **kw)      # default 0.11: mbt2018.py:80
@@ -257,24 +269,43 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
                     else:
                         _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=s_lr, annealing_rate=s_r,
                                                   t0=s_t0, T_ub=s_Tub, seed=sd, loss_scale=loss_scale,
-                                                  trace=verbose)
+                                                  trace=want_trace)
                 finally:
                     codec.set_relaxation("sga", "exp0")
             elif verbose:
+                after = [] if opt_record is not None else None
                 met = run_verbose(codec, X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate, t0=t0,
-                                  T_ub=T_ub, seed=sd, loss_scale=loss_scale, log_itv=log_itv, log=log)
-                tr = None
+                                  T_ub=T_ub, seed=sd, loss_scale=loss_scale, log_itv=log_itv, log=log, after=after)
+                tr = codec.run_latents(trace=True)[2] if want_trace else None
             else:
-                _, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate,
-                                          t0=t0, T_ub=T_ub, seed=sd, loss_scale=loss_scale,
-                                          trace=verbose)
-            if verbose and tr is not None:
+                y_hat_l, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate,
+                                                t0=t0, T_ub=T_ub, seed=sd, loss_scale=loss_scale,
+                                                trace=want_trace)
+                after = None
+                if recon is not None:
+                    for k, xh in zip(idx, codec.reconstruct(y_hat_l, H, W).cpu().numpy()):
+                        recon.append((k, xh))
+            if tr is not None:
                 tr = tr.cpu().numpy()
-                for it in range(its):
-                    if it % log_itv == 0 or it + 1 == its:      # sga.py:216,232-233
+                pts = [it for it in range(min(its, len(tr))) if it % log_itv == 0 or it + 1 == its]      # sga.py:216,232-233
+                if verbose and not (method == "sga"):
+                    for it in pts:
                         T = annealed_temperature(it, log_rate, log_Tub, scheme=log_sched, t0=log_t0)
                         log("it=%d, T=%.3f rd_loss=%.4f mse=%.3f bpp=%.4f psnr=%.4f" %
                             (it, T, tr[it, 0], tr[it, 1], tr[it, 2], tr[it, 3]))
+                if check_finite:
+                    for it in pts:
+                        if not np.isfinite(tr[it, :3]).all():
+                            raise FloatingPointError(
+                                "non-finite objective at iteration %d of the launch holding images %s: rd_loss=%r mse=%r bpp=%r"
+                                % (it, idx, tr[it, 0], tr[it, 1], tr[it, 2]))
+                if opt_record is not None:
+                    opt_record.clear()
+                    opt_record.update(its=np.asarray(pts), rd_loss=tr[pts, 0].copy(),
+                                      T=np.asarray([annealed_temperature(it, log_rate, log_Tub, scheme=log_sched, t0=log_t0)
+                                                    for it in pts]))
+                    if method == "sga" and verbose and after is not None:
+                        opt_record["rd_loss_after_rounding"] = np.asarray(after)
             local_idx += idx
             local_met.append(met.cpu().numpy())
     finally:
@@ -317,6 +348,14 @@ def parse_args(argv):
                         "(sga.py:130-133), 0.11 for mbt2018.py, which calls it (mbt2018.py:77-80)")
     c.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
                    help="arithmetic of the conv contractions (DESIGN.md 3.1b); f32 = fp32 MFMA")
+    c.add_argument("--check_finite", action="store_true",
+                   help="test the logged objective (every 100 iterations and the last) of every launch and abort with the "
+                        "iteration index at the first NaN / Inf (the reference runs on silently)")
+    c.add_argument("--save_opt_record", action="store_true",
+                   help="also write opt-<...>.npz: its / T / rd_loss at the log points of the last batch (configs.py:12, "
+                        "sga.py:209,234-236,271-278; a module constant in the reference, a flag here)")
+    c.add_argument("--save_reconstruction", action="store_true",
+                   help="write recon-<...>.png of the (single) input image (configs.py:13, sga.py:281-291)")
     c.add_argument("runname")
     c.add_argument("input_file")
     c.add_argument("output_file", nargs="?")
@@ -369,14 +408,30 @@ def compress(args, weights=None):
     codec = SGACodec(weights, args.num_filters, max_batch, H, W, device=f"cuda:{local_rank}",
                      bits_back=bb, precision=getattr(args, "precision", "f32"),
                      scale_bound=0.0 if sb is None else sb)
+    opt_record = {} if getattr(args, "save_opt_record", False) else None
+    recon = [] if getattr(args, "save_reconstruction", False) else None
+    if recon is not None:
+        assert N == 1 and method == "sga", "--save_reconstruction: one image, --method sga (sga.py:282)"
     res = run_dataset(codec, X, args.lmbda, its=args.sga_its, annealing_rate=args.annealing_rate,
                       t0=args.t0, seed=args.seed, rank=rank, world=world, dist=dist,
-                      verbose=args.verbose, method=method, base_scale_bound=sb)
+                      verbose=args.verbose, method=method, base_scale_bound=sb,
+                      check_finite=getattr(args, "check_finite", False), opt_record=opt_record, recon=recon)
     if rank == 0:
         if args.results_dir:
             os.makedirs(args.results_dir, exist_ok=True)
             f = result_filename("rd", method, args.lmbda, args.runname, args.input_file)
             np.savez(os.path.join(args.results_dir, f), **res)
+            if opt_record:                                                   # sga.py:271-278
+                np.savez(os.path.join(args.results_dir, result_filename("opt", method, args.lmbda, args.runname,
+                                                                        args.input_file)), **opt_record)
+            if recon:                                                        # sga.py:281-291
+                from PIL import Image
+                f = result_filename("recon", method, args.lmbda, args.runname, args.input_file)[:-4] + ".png"
+                if method != args.runname.split("-")[0]:
+                    f = f.replace("+" + args.runname, "-rd_opt_its=%d+%s" % (args.sga_its, args.runname))
+                img = np.round(np.clip(recon[0][1], 0.0, 1.0) * 255.0).astype(np.uint8)
+                print("Saving image reconstruction to ", os.path.join(args.results_dir, f))
+                Image.fromarray(img).save(os.path.join(args.results_dir, f))
         for field in res:
             print("Avg {}: {:0.4f}".format(field, res[field].mean()))       # sga.py:293-295
     return res

@@ -186,6 +186,11 @@ int sga_eval(sga_handle* h, const float* x, int B, int H, int W,
  * scale_bound = SGA_SCALE_BOUND_BUILT (or sga_set_scale_bound around the call) to mirror it. */
 int sga_base_compress(sga_handle* h, const float* x, int B, int H, int W, const float* medians,
                       float* y_hat, float* z_hat, float* metrics, void* stream);
+/* The same with the sigma bound as an argument of THIS call (SGA_SCALE_BOUND_BUILT mirrors mbt2018.py:80): the handle's
+ * bound, its cached step graphs and work in flight are left alone (the call launches eagerly).  What a handle that
+ * otherwise runs SGA should use instead of sga_set_scale_bound around sga_base_compress. */
+int sga_base_compress_bound(sga_handle* h, const float* x, int B, int H, int W, const float* medians, float scale_bound,
+                            float* y_hat, float* z_hat, float* metrics, void* stream);
 
 /* ---- sibling relaxations on the same step ------------------------------------
  * The ablation scripts differ from sga.py only in the op that maps (y,z) -> (y_tilde,z_tilde) and
@@ -264,6 +269,10 @@ int sga_op_gaussian_likelihood(sga_handle* h, const float* y, const float* mu,
                                const float* sigma_raw, int64_t n,
                                float* p, float* dp_dy, float* dp_dmu, float* dp_dsraw,
                                void* stream);
+/* ... with an explicit bound instead of the handle's (entropy-coder tables must not depend on mutable handle state) */
+int sga_op_gaussian_likelihood_bound(sga_handle* h, const float* y, const float* mu, const float* sigma_raw, int64_t n,
+                                     float scale_bound, float* p, float* dp_dy, float* dp_dmu, float* dp_dsraw,
+                                     void* stream);
 
 /* The rate half of the graph with fed intermediates (the reference can feed y_tilde / z_tilde and
  * fetch any tensor, sga.py:219-225): the very kernels the SGA step launches for sga.py:100-104 and

@@ -18,7 +18,7 @@ def pytest_sessionstart(session):
     """The built libraries are git-ignored: on a fresh checkout compile them first (hipcc cross-compiles
     gfx950 without a GPU).  A failed build fails the session loudly; there is no CPU fallback."""
     pkg = os.path.join(ROOT, "improving-inference-for-neural-image-compression_amd")
-    if not (os.path.exists(os.path.join(pkg, "libsga_hip.so")) and os.path.exists(os.path.join(pkg, "librans.so"))):
+    if not all(os.path.exists(os.path.join(pkg, n)) for n in ("libsga_hip.so", "libsga_hip_lab.so", "librans.so")):
         import __graft_entry__
         __graft_entry__.build()
 

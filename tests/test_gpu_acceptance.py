@@ -32,16 +32,48 @@ TOL_BPP, TOL_PSNR = 1e-3, 0.01          # north_star tolerance
 # ... the small set again against the FLOAT64 oracle (the control of tests/test_oracle.py: float32-vs-float64 oracle runs
 # differ from each other exactly as the HIP path differs from either), and -- when present -- the BENCHMARKED geometry
 # (cfg 2: B = 8, 256^2, C = 192: POST / 256-row LDS-DMA / split gs2.bwd kernels and the two-stream graph over 2000 steps)
+# ... and (round 4) a TRAINED-LIKE operating point: weights fitted on low-pass noise (tests/tools/fit_weights.py: 0.47 bpp /
+# 33 dB, 55 % of y_hat at 0, predicted scales 0.09 .. 4.4 with 8 % below 0.11) in BOTH sigma-bound modes -- `fitted` is the
+# resolvable full-run check of the SGA default (scale_bound = 0, raw sigma: sga.py:130-133), `fitted_b011` of a built layer
 @pytest.mark.parametrize("golden", ["full_run_oracle.json", "full_run_oracle_c192.json", "full_run_oracle_bb.json",
                                     "full_run_oracle_ragged.json", "full_run_oracle_hirate.json",
-                                    "full_run_oracle_f64.json", "full_run_oracle_cfg2.json"])
+                                    "full_run_oracle_f64.json", "full_run_oracle_fitted.json",
+                                    "full_run_oracle_fitted_b011.json"])
 def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir, golden):
-    _acceptance(gpu_out_dir, golden, "f32", "")
+    rep = _acceptance(gpu_out_dir, golden, "f32", "")
+    assert rep["resolves_1e3_bpp"], rep          # these sets are large enough for the tolerance itself to be the bound
 
 
-def test_full_run_bf16x3_mode_within_north_star_tolerance(gpu_out_dir):
-    """The opt-in precision mode (exact 3 x bf16 operand split; not the headline) on the small set."""
-    _acceptance(gpu_out_dir, "full_run_oracle.json", "bf16x3", "_bf16x3")
+def test_full_run_at_the_benchmarked_geometry_is_consistent_with_the_oracle(gpu_out_dir):
+    """cfg 2 (B = 8, 256^2, C = 192; 2.3 CPU-hours per oracle seed).  This set does NOT resolve the north-star tolerance:
+    its runs end at 4.1 bpp with a seed-to-seed sigma of 7e-3 .. 1.3e-2, so the standard error of the mean over the
+    affordable seeds (12 x 8 images: ~7e-4) is of the order of the tolerance (1e-3) itself.  What is asserted is
+    CONSISTENCY -- |mean| <= 3 standard errors, single runs inside the optimiser's own spread, PSNR within 0.01 dB (that one
+    is resolved) -- and the report says `resolves_1e3_bpp: false`.  The 1e-3 criterion at this geometry is carried by the
+    deterministic traces below (300 iterations of an accelerated schedule; all 2000 of the production schedule) and by
+    the resolvable sets at the small geometries in the same sigma-bound mode (`fitted`)."""
+    rep = _acceptance(gpu_out_dir, "full_run_oracle_cfg2.json", "f32", "")
+    assert abs(rep["mean_d_psnr"]) <= TOL_PSNR
+
+
+@pytest.mark.parametrize("golden", ["full_run_oracle.json", "full_run_oracle_fitted.json"])
+def test_full_run_bf16x3_mode_within_north_star_tolerance(gpu_out_dir, golden):
+    """The opt-in precision mode (exact 3 x bf16 operand split; `alt_precision` of bench.py, not the
+    headline) on the small set and on the trained-like one."""
+    rep = _acceptance(gpu_out_dir, golden, "bf16x3", "_bf16x3")
+    assert rep["resolves_1e3_bpp"], rep
+
+
+def _inputs(cfg):
+    if cfg.get("inputs") == "lowpass":
+        return sga_amd.make_lowpass_images(cfg["B"], cfg["H"], cfg["W"], seed=cfg["x_seed"])
+    return np.random.RandomState(cfg["x_seed"]).rand(cfg["B"], cfg["H"], cfg["W"], 3).astype(np.float32)
+
+
+def _weights(cfg):
+    if cfg.get("weights"):      # "fitted_c64" -> tests/golden/fitted_weights_c64.npz (tests/tools/fit_weights.py)
+        return sga_amd.load_weights_npz(os.path.join(ROOT, "tests", "golden", "fitted_weights_%s.npz" % cfg["weights"].split("_")[1]))
+    return sga_amd.make_synthetic_weights(cfg["C"], seed=cfg["weight_seed"], bb=bool(cfg.get("bb")))
 
 
 def _acceptance(gpu_out_dir, golden, precision, tag):
@@ -53,9 +85,8 @@ def _acceptance(gpu_out_dir, golden, precision, tag):
         gold = json.load(f)
     cfg = gold["config"]
     C, B, H, W = cfg["C"], cfg["B"], cfg["H"], cfg["W"]
-    x = np.random.RandomState(cfg["x_seed"]).rand(B, H, W, 3).astype(np.float32)
+    x, w = _inputs(cfg), _weights(cfg)
     bb = bool(cfg.get("bb"))
-    w = sga_amd.make_synthetic_weights(C, seed=cfg["weight_seed"], bb=bb)
     # the sets of rounds 1-2 were generated with the 0.11 sigma bound hard-coded; the cfg-2 set with the default
     # (0: sga.py:130-133 never builds the tfc layer).  The HIP path runs in the mode its golden set was made in.
     codec = SGACodec(w, C, B, H, W, precision=precision, bits_back=bb, scale_bound=cfg.get("scale_bound", 0.11))
@@ -99,7 +130,11 @@ def _acceptance(gpu_out_dir, golden, precision, tag):
     # ~1e-3 -- the bound is 3 standard errors (a criterion tighter than the noise cannot be tested), the report states
     # both, and the deterministic trace test below carries the weight for that geometry.
     resolvable = rep["sem_d_bpp"] <= TOL_BPP / 3
-    rep["criterion_bpp"] = "abs(mean) <= 1e-3" if resolvable else "abs(mean) <= 3 standard errors (set too small for 1e-3)"
+    rep["resolves_1e3_bpp"] = bool(resolvable)
+    rep["criterion_bpp"] = "abs(mean) <= 1e-3 (the north-star tolerance)" if resolvable else \
+        "CONSISTENCY ONLY: abs(mean) <= 3 standard errors; this set cannot resolve 1e-3 and does not claim it"
+    with open(os.path.join(gpu_out_dir, golden.replace("full_run_oracle", "acceptance_full_run").replace(".json", tag + ".json")), "w") as f:
+        json.dump(rep, f, indent=1)
     assert abs(rep["mean_d_bpp"]) <= (TOL_BPP if resolvable else 3 * rep["sem_d_bpp"]), rep
     assert abs(rep["mean_d_psnr"]) <= TOL_PSNR, rep
     if bb:
@@ -126,6 +161,7 @@ def _acceptance(gpu_out_dir, golden, precision, tag):
     # 5-seed set at the benchmarked geometry)
     lo, hi = (0.5, 2.0) if len(gold["runs"]) >= 16 else (0.3, 3.3)
     assert (ratio > lo).all() and (ratio < hi).all(), rep
+    return rep
 
 
 def test_trace_at_the_benchmarked_geometry(gpu_out_dir):
@@ -144,8 +180,8 @@ def test_trace_at_the_benchmarked_geometry(gpu_out_dir):
         gold = json.load(f)
     cfg, run = gold["config"], gold["runs"][0]
     C, B, H, W = cfg["C"], cfg["B"], cfg["H"], cfg["W"]
-    x = np.random.RandomState(cfg["x_seed"]).rand(B, H, W, 3).astype(np.float32)
-    codec = SGACodec(sga_amd.make_synthetic_weights(C, seed=cfg["weight_seed"]), C, B, H, W, scale_bound=cfg["scale_bound"])
+    x = _inputs(cfg)
+    codec = SGACodec(_weights(cfg), C, B, H, W, scale_bound=cfg["scale_bound"])
     want = np.array(run["trace"])
     outs = []
     for _ in range(2):
@@ -165,4 +201,53 @@ def test_trace_at_the_benchmarked_geometry(gpu_out_dir):
     assert want[-1, 0] < 0.9 * want[0, 0]                           # the run really optimises over these iterations
     assert (rel[:100, :3] < 1e-4).all(), rep
     assert (rel[:, :3] < 1e-3).all() and (np.abs(got[:, 3] - want[:, 3]) < 0.01).all(), rep
+    codec.close()
+
+
+def test_trace_2000_at_the_production_schedule(gpu_out_dir):
+    """cfg 2 under the PRODUCTION schedule (t0 = 700, rate 1e-3: sga.py:193-196), all 2000 iterations, step by step against
+    the oracle's committed trace of the same run (`full_run_oracle_cfg2trace2000.json` = seed 0 of the cfg-2 golden set
+    with its per-iteration scalars kept; 2.3 CPU-hours).  Both sides draw identical Philox noise, so the two float32
+    trajectories ARE one trajectory until rounding differences have flipped enough floor / ceil decisions to show in the
+    batch scalars; from then on they are two draws of the same stochastic optimiser.  Reported: the first iteration at
+    which the relative rd_loss difference exceeds 1e-6 / 1e-5 / 1e-4 / 1e-3 and the maximum over four windows.  Asserted:
+    rd_loss, train_mse and train_bpp within 1e-4 (relative) over the first 300 iterations -- T is at its upper bound for
+    700 iterations under this schedule, the regime the accelerated 300-iteration trace test never sees -- and within
+    3e-3 afterwards (3 sigma of the seed-to-seed spread of the batch-mean bpp at this geometry: sigma_image 7e-3 .. 1.3e-2
+    of 4.1 bpp over 8 images), mean PSNR within 0.01 dB throughout, and the end point within the same bounds."""
+    from sga_amd.codec import SGACodec
+    path = os.path.join(ROOT, "tests", "golden", "full_run_oracle_cfg2trace2000.json")
+    if not os.path.exists(path):
+        pytest.skip("full_run_oracle_cfg2trace2000.json not generated yet (GOLDEN=cfg2trace2000 tests/tools/make_golden_full_run.py)")
+    with open(path) as f:
+        gold = json.load(f)
+    cfg, run = gold["config"], gold["runs"][0]
+    C, B, H, W = cfg["C"], cfg["B"], cfg["H"], cfg["W"]
+    codec = SGACodec(_weights(cfg), C, B, H, W, scale_bound=cfg["scale_bound"])
+    want = np.array(run["trace"])
+    y_hat, z_hat, met, tr = codec.run(_inputs(cfg), cfg["lmbda"], its=cfg["its"], seed=run["seed"], trace=True)
+    got = tr.cpu().numpy().astype(np.float64)
+    rel = np.abs(got / want - 1)
+
+    def first_above(th):
+        idx = np.nonzero(rel[:, 0] > th)[0]
+        return int(idx[0]) if idx.size else None
+
+    windows = [(0, 100), (100, 300), (300, 1000), (1000, cfg["its"])]
+    from sga_amd.codec import metrics_to_dict
+    m = metrics_to_dict(met)
+    rep = dict(its=int(cfg["its"]), first_iteration_rel_rd_loss_above={"1e-6": first_above(1e-6), "1e-5": first_above(1e-5),
+                                                                       "1e-4": first_above(1e-4), "1e-3": first_above(1e-3)},
+               max_rel_by_window={"%d-%d" % w: rel[w[0]:w[1], :3].max(0).tolist() for w in windows},
+               max_abs_d_mean_psnr=float(np.abs(got[:, 3] - want[:, 3]).max()),
+               rd_loss_first=float(want[0, 0]), rd_loss_last=float(want[-1, 0]), rd_loss_last_hip=float(got[-1, 0]),
+               end_d_bpp_mean=float(m["est_bpp"].mean() - np.mean(run["est_bpp"])),
+               end_d_psnr_mean=float(m["psnr"].mean() - np.mean(run["psnr"])),
+               frac_nonzero_y_hat_oracle=run.get("frac_nonzero_y_hat"), frac_nonzero_y_hat_hip=float((y_hat != 0).float().mean()))
+    with open(os.path.join(gpu_out_dir, "acceptance_trace2000_cfg2.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    print(json.dumps(rep))
+    assert (rel[:300, :3] < 1e-4).all(), rep
+    assert (rel[:, :3] < 3e-3).all() and (np.abs(got[:, 3] - want[:, 3]) < 0.01).all(), rep
+    assert abs(rep["end_d_bpp_mean"]) < 3e-3 * 4.1 and abs(rep["end_d_psnr_mean"]) < 0.01, rep
     codec.close()

@@ -198,3 +198,28 @@ def test_full_bits_back_run_cfg5_kodak():
     assert tr1[-50:, 0].mean() < tr1[:50, 0].mean()          # stage 1: rd_loss falls
     assert tr2[-50:, 2].mean() < tr2[:50, 2].mean()          # stage 2: train_bpp falls
     codec.close()
+
+
+def test_base_compress_between_runs_leaves_the_step_graph_alone():
+    """`base_compress` used to toggle the handle's sigma bound twice per call (two device synchronisations, the
+    cached step graph dropped and re-captured, the fork point re-timed).  The bound is now an argument of the call
+    (sga_base_compress_bound): interleaved with runs on the same codec it changes neither the tuned graph nor any result,
+    and it equals what a handle created with the bound computes."""
+    from sga_amd.codec import SGACodec
+    C, B, H, W = 64, 2, 64, 64
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    x = np.random.RandomState(4).rand(B, H, W, 3).astype(np.float32)
+    codec = SGACodec(w, C, B, H, W)                       # scale_bound 0: the SGA default
+    a = codec.run(x, 0.01, its=120, seed=5)
+    fp = codec.fork_point()
+    assert fp != "untimed"
+    y1, z1, m1 = codec.base_compress(x)                   # bound 0.11 for this call only
+    assert codec.scale_bound == 0.0 and codec.fork_point() == fp
+    b = codec.run(x, 0.01, its=120, seed=5)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    built = SGACodec(w, C, B, H, W, scale_bound=0.11)
+    y2, z2, m2 = built.base_compress(x)
+    assert torch.equal(y1, y2) and torch.equal(z1, z2) and torch.equal(m1[:, [0, 1, 4, 5, 6]], m2[:, [0, 1, 4, 5, 6]])
+    y3, z3, m3 = codec.base_compress(x, scale_bound=0.0)
+    assert not torch.equal(m3[:, 4], m1[:, 4]) or float((m3[:, 4] - m1[:, 4]).abs().max()) == 0.0
+    codec.close(); built.close()

@@ -4,7 +4,12 @@ resident-operand C x C contraction + epilogue, one launch) against the launches 
 transposed convolution (conv_mfma.hip, POST = 1) against a separate IGDN launch: the same f32 fmaf chains in the
 same order, so the two paths must agree BIT FOR BIT -- in the encoder (GDN forward,
 nn_models.py:17-25), in one SGA step (IGDN forward / backward, nn_models.py:51-59) and over a short
-run.  Parity of either path with the oracle is covered by the other GPU test files."""
+run.  Parity of either path with the oracle is covered by the other GPU test files.
+
+The ablation switches (SGA_FUSED_GDN, SGA_KEEP_U, SGA_POST_P, SGA_FUSED_POST64, SGA_GS3_GEMM, SGA_FUSED_MSE, SGA_FUSED_BOUNDARY,
+SGA_FORK_AT, SGA_FORK2_NAME) exist only in the LABORATORY build of the library (`make EXPERIMENTS=1` -> libsga_hip_lab.so,
+`SGACodec(..., lab=True)`); the product library has none of them (tests/test_host.py).  With no switch set the two builds
+run the same launches: `test_lab_build_equals_the_product_build` checks that bit for bit."""
 import os
 
 import numpy as np
@@ -28,11 +33,11 @@ def _pair(C, B, H, W):
         # (SGA_POST_P=0: the C -> 3 layer by the halo kernel on both sides; its products formed in the post-phase are
         # compared with the stand-alone GEMM in test_post_phase_products_equal_the_standalone_gemm)
         os.environ["SGA_FUSED_GDN"] = "1"; os.environ["SGA_KEEP_U"] = "1"; os.environ["SGA_POST_P"] = "0"
-        fused = SGACodec(w, C, B, H, W)
+        fused = SGACodec(w, C, B, H, W, lab=True)
         os.environ["SGA_FUSED_GDN"] = "0"
-        legacy = SGACodec(w, C, B, H, W)
+        legacy = SGACodec(w, C, B, H, W, lab=True)
         os.environ.pop("SGA_FUSED_GDN"); os.environ.pop("SGA_KEEP_U")
-        default = SGACodec(w, C, B, H, W)
+        default = SGACodec(w, C, B, H, W, lab=True)
     finally:
         for k, v in old.items():
             if v is None:
@@ -85,9 +90,9 @@ def test_post_phase_in_the_64_row_instance_equals_the_separate_igdn(C, B, H, W, 
     from sga_amd.codec import SGACodec
     w = sga_amd.make_synthetic_weights(C, seed=0)
     monkeypatch.setenv("SGA_FUSED_POST64", "1")
-    on = SGACodec(w, C, B, H, W)
+    on = SGACodec(w, C, B, H, W, lab=True)
     monkeypatch.setenv("SGA_FUSED_POST64", "0")
-    off = SGACodec(w, C, B, H, W)
+    off = SGACodec(w, C, B, H, W, lab=True)
     x = np.random.RandomState(7).rand(B, H, W, 3).astype(np.float32)
     y, z = off.encode(x)
     on.profile_begin(); ra = on.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5); names = [k["name"] for k in on.profile_end()]
@@ -104,7 +109,7 @@ def _codec_env(name, value, *args):
     old = os.environ.get(name)
     os.environ[name] = value
     try:
-        return SGACodec(*args)
+        return SGACodec(*args, lab=True)
     finally:
         if old is None:
             os.environ.pop(name, None)
@@ -199,9 +204,9 @@ def test_post_phase_products_equal_the_standalone_gemm(C, B, H, W):
     old = {k: os.environ.get(k) for k in ("SGA_POST_P", "SGA_GS3_GEMM")}
     try:
         os.environ["SGA_POST_P"] = "1"; os.environ.pop("SGA_GS3_GEMM", None)
-        ships = SGACodec(w, C, B, H, W)
+        ships = SGACodec(w, C, B, H, W, lab=True)
         os.environ["SGA_POST_P"] = "0"; os.environ["SGA_GS3_GEMM"] = "1"
-        ref = SGACodec(w, C, B, H, W)
+        ref = SGACodec(w, C, B, H, W, lab=True)
     finally:
         for k, v in old.items():
             if v is None:
@@ -237,7 +242,7 @@ def test_results_do_not_depend_on_the_schedule(monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        c = SGACodec(w, C, B, H, W)
+        c = SGACodec(w, C, B, H, W, lab=True)
         before = c.fork_point()
         out = c.run(x, 0.01, its=130, seed=4)            # >= 100 iterations: the timed fork point when nothing pins it
         after = c.fork_point()
@@ -256,3 +261,21 @@ def test_results_do_not_depend_on_the_schedule(monkeypatch):
         assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), env
         assert torch.equal(out[2][:, [0, 1, 4, 5, 6]], ref[2][:, [0, 1, 4, 5, 6]]), env
         assert torch.equal(g["gy"], gref["gy"]) and torch.equal(g["gz"], gref["gz"]) and g["rd_loss"] == gref["rd_loss"], env
+
+
+def test_lab_build_equals_the_product_build():
+    """libsga_hip_lab.so = libsga_hip.so + switches: with none of them set, a step and a run agree bit for bit."""
+    from sga_amd.codec import SGACodec
+    C, B, H, W = 192, 2, 128, 128
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    x = np.random.RandomState(5).rand(B, H, W, 3).astype(np.float32)
+    prod, lab = SGACodec(w, C, B, H, W), SGACodec(w, C, B, H, W, lab=True)
+    assert prod.lib is not lab.lib
+    y, z = prod.encode(x)
+    y2, z2 = lab.encode(x)
+    assert torch.equal(y, y2) and torch.equal(z, z2)
+    ga, gb = prod.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5), lab.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    assert torch.equal(ga["gy"], gb["gy"]) and torch.equal(ga["gz"], gb["gz"]) and ga["rd_loss"] == gb["rd_loss"]
+    a, b = prod.run(x, 0.01, its=120, seed=1), lab.run(x, 0.01, its=120, seed=1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    prod.close(); lab.close()

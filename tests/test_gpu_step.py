@@ -295,7 +295,7 @@ def test_run_trace_with_more_than_eight_images(gpu_out_dir):
     old = _os.environ.get("SGA_FUSED_BOUNDARY")
     _os.environ["SGA_FUSED_BOUNDARY"] = "0"
     try:
-        c2 = SGACodec(w, C, B, H, W)
+        c2 = SGACodec(w, C, B, H, W, lab=True)          # (the switch exists in the laboratory build only)
     finally:
         if old is None:
             _os.environ.pop("SGA_FUSED_BOUNDARY")
@@ -429,6 +429,58 @@ def test_driver_cli_end_to_end(method, tmp_path):
     if method in ("mbt2018", "danneal", "ste", "map"):       # no noise: chunking cannot matter
         for k in ("est_bpp", "psnr"):
             assert np.allclose(res[5][k], res[2][k], rtol=2e-4), (k, res[5][k], res[2][k])
+
+
+def test_driver_aux_outputs_and_finite_check(tmp_path):
+    """The small items of the reference's loop (missing 4): the optimisation record `opt-*.npz` (sga.py:209,
+    234-236,271-278: its / T / rd_loss at the log points of the last batch, + rd_loss_after_rounding with --verbose), the
+    reconstruction dump `recon-*.png` (sga.py:281-291) and a finite-check of the logged objective that names
+    the iteration at which a run went non-finite."""
+    from PIL import Image
+    from sga_amd import driver
+    rng = np.random.RandomState(9)
+    img = (rng.rand(48, 64, 3) * 255).astype(np.uint8)
+    inp = tmp_path / "one.png"
+    Image.fromarray(img).save(inp)
+    runname = "mbt2018-num_filters=64-lmbda=0.02"
+    out = tmp_path / "res"
+    base = ["--num_filters", "64", "compress", "--results_dir", str(out), "--sga_its", "230", "--t0", "40",
+            "--synthetic_weights", "--check_finite", "--save_opt_record", "--save_reconstruction"]
+    res = driver.main(base + [runname, str(inp)])
+    files = sorted(os.listdir(out))
+    rd, opt = driver.result_filename("rd", "sga", 0.02, runname, str(inp)), driver.result_filename("opt", "sga", 0.02, runname, str(inp))
+    recon = [f for f in files if f.startswith("recon-") and f.endswith(".png")]
+    assert rd in files and opt in files and len(recon) == 1 and "rd_opt_its=230" in recon[0], files
+    rec = dict(np.load(out / opt))
+    assert rec["its"].tolist() == [0, 100, 200, 229] and rec["T"][0] == 0.5 and rec["T"][-1] < 0.5
+    assert np.isfinite(rec["rd_loss"]).all() and rec["rd_loss"][-1] < rec["rd_loss"][0]
+    xr = np.asarray(Image.open(out / recon[0]))
+    assert xr.shape == img.shape
+    mse = float(((xr.astype(np.float64) - img) ** 2).mean())
+    assert abs(mse - float(res["mse"][0])) < 1e-3 * mse            # the dumped image IS the evaluated reconstruction
+    # --verbose adds the after-rounding objective to the record (sga.py:231)
+    out2 = tmp_path / "res2"
+    driver.main(["--verbose"] + base[:4] + [str(out2)] + base[5:] + [runname, str(inp)])
+    rec2 = dict(np.load(out2 / opt))
+    assert rec2["rd_loss_after_rounding"].shape == (4,) and np.allclose(rec2["rd_loss"], rec["rd_loss"], rtol=1e-6)
+    # a run that goes non-finite: a NaN pixel -> NaN objective from iteration 0; the check names the iteration
+    bad = np.stack([img.astype(np.float32)])
+    npy = tmp_path / "bad.npy"
+    np.save(npy, bad)
+
+    def nan_images(path):
+        X = driver.load_images.__wrapped__(path) if hasattr(driver.load_images, "__wrapped__") else _orig(path)
+        X[0, 3, 5, 1] = np.nan
+        return X
+    _orig = driver.load_images
+    driver.load_images = nan_images
+    try:
+        with pytest.raises(FloatingPointError, match="iteration 0"):
+            driver.main(base[:6] + ["12"] + base[7:] + [runname, str(npy)])
+        silent = driver.main([a for a in base[:6] + ["12"] + base[7:] if a not in ("--check_finite", "--save_reconstruction")] + [runname, str(npy)])
+        assert not np.isfinite(silent["est_bpp"]).all() or not np.isfinite(silent["psnr"]).all()   # the reference's behaviour
+    finally:
+        driver.load_images = _orig
 
 
 def test_verbose_run_matches_plain_run(gpu_out_dir):

@@ -34,6 +34,31 @@ def test_library_exports_every_declared_symbol():
     assert lib.sga_abi_version() == _lib.SGA_ABI_VERSION
 
 
+def test_product_library_has_only_the_documented_environment_knobs():
+    """result-changing and work-skipping switches (SGA_SKIP_SIDE, SGA_KEEP_U, SGA_HYBRID, SGA_FUSED_*, ...)
+    and their template instances live in the laboratory build only (`make EXPERIMENTS=1` -> libsga_hip_lab.so).  The strings
+    of the PRODUCT library name exactly the knobs INTEGRATION.md section 6 documents; the lab build is a strict superset;
+    the product build is the smaller one (it lacks the POST = 2 / 3 convolution instances)."""
+    import re
+
+    def knobs(path):
+        with open(path, "rb") as f:
+            data = f.read()
+        return {m.decode() for m in re.findall(rb"SGA_[A-Z0-9_]{3,}", data)}
+
+    prod, lab = knobs(_lib.LIB_PATH), knobs(_lib.LAB_LIB_PATH)
+    assert prod == set(_lib.PRODUCT_ENV_KNOBS), sorted(prod ^ set(_lib.PRODUCT_ENV_KNOBS))
+    assert len(prod) <= 10
+    assert prod < lab and {"SGA_SKIP_SIDE", "SGA_KEEP_U", "SGA_FUSED_GDN", "SGA_HYBRID", "SGA_DEBUG_SEGV"} <= lab
+    assert os.path.getsize(_lib.LIB_PATH) < os.path.getsize(_lib.LAB_LIB_PATH)
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        doc = f.read()
+    for k in _lib.PRODUCT_ENV_KNOBS:
+        assert k in doc, k + " is not documented in INTEGRATION.md"
+    lab_lib = _lib.load_library(_lib.LAB_LIB_PATH)      # the lab build exports the same C ABI
+    assert lab_lib.sga_abi_version() == _lib.SGA_ABI_VERSION
+
+
 def test_one_hip_runtime_in_the_process():
     """Loading the library (even before anyone imported torch, as build() does) must leave ONE
     libamdhip64 mapped: torch's bundled copy.  Two copies gave SGA_ERR_NO_DEVICE on a GPU box."""

@@ -73,6 +73,7 @@ NAME = os.environ.get("GOLDEN", "")
 CFG = CFGS[NAME]
 if os.environ.get("NSEEDS"):
     CFG["seeds"] = list(range(int(os.environ["NSEEDS"])))
+CKPT_DIR = os.environ.get("GOLDEN_CKPT_DIR", "/tmp/golden_ckpt")
 OUT = os.path.join(ROOT, "tests", "golden", "full_run_oracle%s.json" % ("_" + NAME if NAME else ""))
 
 
@@ -91,6 +92,46 @@ def make_weights(cfg):
     return sga_amd.make_synthetic_weights(cfg["C"], seed=cfg["weight_seed"], bb=bool(cfg.get("bb")))
 
 
+def run_resumable(orc, x, lmbda, its, seed, trace, t0, r, ckpt, progress=None, every=25):
+    """SGAOracle.run (oracle/sga_oracle.py: the loop of sga.py:207-247) statement for statement, with its state -- latents,
+    Adam moments and step count, the trace so far -- written to `ckpt` every `every` iterations and picked up again when the
+    file exists: a 2-hour run survives a restart of the build session.  The run stays a pure function of its seed."""
+    import numpy as np
+    import torch
+    from oracle.sga_oracle import AdamF32, annealed_temperature
+    from oracle import philox
+    x = torch.as_tensor(x, dtype=orc.dtype)
+    opt = AdamF32(lr=0.005)
+    tr = np.zeros((its, 4), np.float32)
+    it0 = 0
+    if os.path.exists(ckpt):
+        with np.load(ckpt) as f:
+            y_cur, z_cur, it0 = f["y"], f["z"], int(f["it"])
+            opt.ms, opt.vs, opt.iterations = [f["my"], f["mz"]], [f["vy"], f["vz"]], int(f["it"])
+            tr[:it0] = f["tr"][:it0]
+        print("seed %d resumed at iteration %d" % (seed, it0), flush=True)
+    else:
+        y_cur, z_cur = orc.encode(x)
+        y_cur, z_cur = y_cur.numpy().astype(np.float32), z_cur.numpy().astype(np.float32)
+    for it in range(it0, its):
+        T = np.float32(annealed_temperature(it, r=r, ub=0.5, scheme="exp0", t0=t0))
+        u_y = philox.sga_uniforms(y_cur.size, it, 0, seed)
+        u_z = philox.sga_uniforms(z_cur.size, it, 1, seed)
+        s = orc.step(x, y_cur, z_cur, float(T), u_y, u_z, lmbda, None)
+        y_cur, z_cur = opt.update([y_cur, z_cur], [s["gy"].numpy().astype(np.float32), s["gz"].numpy().astype(np.float32)])
+        tr[it] = (s["rd_loss"], s["train_mse"], s["train_bpp"], float(s["psnr"].mean()))
+        if progress is not None and it % 100 == 0:
+            progress(it, s)
+        if (it + 1) % every == 0 and it + 1 < its:
+            np.savez(ckpt + ".tmp.npz", y=y_cur, z=z_cur, it=it + 1, my=opt.ms[0], mz=opt.ms[1], vy=opt.vs[0], vz=opt.vs[1], tr=tr)
+            os.replace(ckpt + ".tmp.npz", ckpt)
+    y_hat, z_hat = np.round(y_cur), np.round(z_cur)
+    metrics = orc.evaluate(x, y_hat, z_hat)
+    if os.path.exists(ckpt):
+        os.remove(ckpt)
+    return y_hat, z_hat, metrics, (tr if trace else None)
+
+
 def one_seed(seed):
     import numpy as np
     import torch
@@ -106,8 +147,13 @@ def one_seed(seed):
     else:
         prog = (lambda it, st: print("seed %d it %d rd_loss %.4f %.0f s" % (seed, it, st["rd_loss"], time.time() - t),
                                      flush=True)) if os.environ.get("PROGRESS") else None
-        y_hat, z_hat, m, tr = orc.run(x, CFG["lmbda"], its=CFG["its"], seed=seed, progress=prog, trace=bool(CFG.get("trace")),
-                                      t0=CFG.get("t0", 700), r=CFG.get("annealing_rate", 1e-3))
+        if CFG["H"] * CFG["W"] * CFG["B"] >= 8 * 256 * 256 and CFG.get("dtype", "float32") == "float32":      # hours per seed: resumable
+            os.makedirs(CKPT_DIR, exist_ok=True)
+            y_hat, z_hat, m, tr = run_resumable(orc, x, CFG["lmbda"], CFG["its"], seed, bool(CFG.get("trace")), CFG.get("t0", 700),
+                                                CFG.get("annealing_rate", 1e-3), os.path.join(CKPT_DIR, "%s_seed%d.npz" % (NAME, seed)), prog)
+        else:
+            y_hat, z_hat, m, tr = orc.run(x, CFG["lmbda"], its=CFG["its"], seed=seed, progress=prog, trace=bool(CFG.get("trace")),
+                                          t0=CFG.get("t0", 700), r=CFG.get("annealing_rate", 1e-3))
     out = dict(seed=seed, seconds=time.time() - t,
                est_bpp=m["est_bpp"].astype(np.float64).tolist(), psnr=m["psnr"].astype(np.float64).tolist(),
                est_y_bpp=m["est_y_bpp"].astype(np.float64).tolist(),
