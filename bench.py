@@ -105,8 +105,12 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
                     help="arithmetic of the conv contractions for the HEADLINE value: f32 = "
                          "v_mfma_f32_32x32x2_f32 (default); bf16x3 = exact 3 x bf16 operand split")
-    ap.add_argument("--alt-precision", action="store_true",
-                    help="also measure the other precision mode (opt-in; the bf16x3 mode is not part of the headline)")
+    ap.add_argument("--alt-precision", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--no-alt-precision", action="store_true",
+                    help="skip the secondary measurement of the other precision mode (bf16x3: exact 3 x bf16 operand split on the "
+                         "bf16 matrix pipe, f32 accumulate; reported as `alt_precision`, never the headline)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip `other_configs`: one timed 2000-iteration run each at BASELINE.md section 4's other shapes")
     ap.add_argument("--dump-metrics", default="",
                     help="write the gathered [n_gpus*B, 7] metrics of the last timed step to this .npy (tests)")
     ap.add_argument("--input", default="uniform", choices=["uniform", "natural"],
@@ -121,7 +125,8 @@ def main():
                          "profiles/r01_c_roofline_leg_kernel_stats.csv was taken from with rocprofv3 --kernel-trace --stats)")
     args = ap.parse_args()
     if args.roofline_only:
-        args.warmup, args.steps, args.no_cpu_baseline, args.alt_precision, args.no_other_input = 0, 0, True, False, True
+        args.warmup, args.steps, args.no_cpu_baseline, args.no_alt_precision, args.no_other_input = 0, 0, True, True, True
+        args.no_other_configs = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -260,21 +265,28 @@ def main():
         except (OSError, ValueError):
             pass
 
-    # ---- secondary measurement: the other precision mode, same workload ---------------------------
+    # ---- secondary measurement: the other precision mode, same workload (one warm-up + 3 timed steps) -----------
     alt = None
-    if rank == 0 and world == 1 and args.alt_precision:
+    if rank == 0 and world == 1 and args.steps and not args.no_alt_precision:
         other = "bf16x3" if args.precision == "f32" else "f32"
         codec2 = SGACodec(weights, C, B, H, W, device=device, precision=other)
         one_step(0, codec2)
         torch.cuda.synchronize(device)
+        nalt = min(args.steps, 3)
         t1 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(nalt):
             met2 = one_step(100 + i, codec2)
         torch.cuda.synchronize(device)
         el2 = time.perf_counter() - t1
-        alt = dict(precision=other, value=round(B * args.steps / el2, 4),
-                   ms_per_step=round(1e3 * el2 / args.steps, 2),
-                   final_est_bpp_mean=float(met2[:, 4].mean()), final_psnr_mean=float(met2[:, 1].mean()))
+        alt = dict(precision=other, value=round(B * nalt / el2, 4), steps=nalt,
+                   ms_per_step=round(1e3 * el2 / nalt, 2), ms_per_iteration=round(1e3 * el2 / nalt / args.its, 4),
+                   path_frac_of_fp32_mfma_peak=round(B * nalt / el2 * gflop_per_image_step(H, W, C) * args.its / 1e3
+                                                     / FP32_MFMA_PEAK_TFLOPS, 4),
+                   hyper_branch_fork_point=codec2.fork_point(),
+                   final_est_bpp_mean=float(met2[:, 4].mean()), final_psnr_mean=float(met2[:, 1].mean()),
+                   note="same algorithmic FLOPs on the bf16 matrix pipe: every f32 operand split exactly into 3 bf16 planes, 6 "
+                        "plane products per MAC, f32 accumulate (f32-grade accuracy; DESIGN.md 3.6); a fraction of the fp32-MFMA "
+                        "peak above 1 is possible in this mode and is not a claim about the f32 roofline")
         if not args.no_kernel_profile:
             codec2.profile_begin()
             codec2.run(x, args.lmbda, its=min(args.its, 60), seed=7, metrics=False)
@@ -284,6 +296,38 @@ def main():
                 alt["dominant_kernel"] = dict(name=k2[0]["name"], algorithmic_tflops=round(a2, 2),
                                               avg_launch_us=round(1e3 * k2[0]["ms_total"] / k2[0]["launches"], 2))
         codec2.close()
+
+    # ---- BASELINE.md section 4's other shapes: one timed complete run each (N = 1 only) -------------------------------
+    other_configs = None
+    if rank == 0 and world == 1 and args.steps and not args.no_other_configs and args.its >= 200:
+        other_configs = []
+        shapes = [("cfg2 B=1", C, 1, H, W, args.lmbda), ("cfg2 B=32", C, 32, H, W, args.lmbda),
+                  ("cfg3 Kodak, 3 x 512x768 per GPU", 192, 3, 512, 768, 0.01),
+                  ("cfg4 Tecnick, 1 x 1200x1200, num_filters=256, lambda=0.08", 256, 1, 1200, 1200, 0.08)]
+        wcache = {C: weights}
+        for name, Cc, Bc, Hc, Wc, lam in shapes:
+            try:
+                if Cc not in wcache:
+                    wcache[Cc] = sga_amd.make_synthetic_weights(Cc, seed=0)
+                cdc = SGACodec(wcache[Cc], Cc, Bc, Hc, Wc, device=device, precision=args.precision)
+                xc = torch.rand(Bc, Hc, Wc, 3, generator=torch.Generator(device="cpu").manual_seed(2000 + Bc)).to(device)
+                cdc.run(xc, lam, its=110, seed=1, metrics=False)        # captures the step graph, times the fork point
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                _, _, mc, _ = cdc.run(xc, lam, its=args.its, seed=2)
+                torch.cuda.synchronize(device)
+                el = time.perf_counter() - t1
+                tf_img = gflop_per_image_step(Hc, Wc, Cc) * args.its / 1e3
+                other_configs.append(dict(config=name, batch=Bc, value=round(Bc / el, 4), unit="images/sec",
+                                          ms_per_iteration=round(1e3 * el / args.its, 4),
+                                          path_frac_of_fp32_mfma_peak=round(Bc / el * tf_img / FP32_MFMA_PEAK_TFLOPS, 4),
+                                          tflop_per_image=round(tf_img, 2), hyper_branch_fork_point=cdc.fork_point(),
+                                          final_est_bpp_mean=float(mc[:, 4].mean()), final_psnr_mean=float(mc[:, 1].mean())))
+                cdc.close()
+                del cdc, xc
+                torch.cuda.empty_cache()
+            except Exception as e:      # measurement only: never fail the bench line for it
+                other_configs.append(dict(config=name, error=str(e)[:200]))
 
     tf_per_image = gflop_per_image_step(H, W, C) * args.its / 1e3
     path_frac = value / world * tf_per_image / FP32_MFMA_PEAK_TFLOPS
@@ -317,6 +361,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "alt_precision": alt,
+            "other_configs": other_configs,
             "path_frac_of_fp32_mfma_peak": round(path_frac, 4),
             "tflop_per_image": round(tf_per_image, 3),
             "final_est_bpp_mean": float(np.mean(m[:, 4])), "final_psnr_mean": float(np.mean(m[:, 1])),

@@ -95,10 +95,16 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // C = 192: 128 x 196 + 2 x 192 x 36 floats = 152 KB;  C = 256 (README.md:58-60, cfg 4): 64 x 260 + 2 x 256 x 36 = 137 KB.
 // The 64-row 4-wave instance (two workgroups per CU; layer 1 at cfg 2) holds its whole tile and ONE gamma chunk:
 // 64 x 196 + 192 x 36 floats = 78 KB, the footprint of gdn_tile_kernel, whose launch it replaces.
+// bf16x3, PRO_NONE instances: the K loop in 16-wide stages through TWO LDS stages of unpadded 32-byte rows per plane (see the
+// X3P block in the kernel); the prologue-transform instances keep the single-stage 32-wide loop
+constexpr bool x3_pipelined(int PRO, bool SMALLC, bool X3) { return X3 && !SMALLC && PRO == PRO_NONE; }
+constexpr int x3_main_floats(int BM, int BN, bool pipelined) {
+  return pipelined ? 2 * 3 * (BM + BN) * 32 / 4 : 3 * (BM + BN) * X3_PITCH / 4;
+}
 constexpr int post_rows(int BM, int BN) { return BM < 128 ? BM : (BN <= 192 ? 128 : 64); }
 constexpr int post_qbufs(int BM) { return BM < 128 ? 1 : 2; }
 template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3, int POST = 0>
-__global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || WM * WN >= 8)) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN >= 8)) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int RPP = NT / 8;                 // tile rows covered by one pass of the loaders
@@ -113,7 +119,8 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || WM * WN >= 8)) ? 1
   // 256-row instance (gs2.bwd holds every CU from start to end; the branch's backward half otherwise waits for it)
   constexpr bool LOWF = POST == 3;
   constexpr bool HASPOST = POST == 1 || POST == 2;
-  constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (GLDS ? (LOWF ? 1 : 2) * (BM + BN) * 32 : (BM + BN) * LDK);
+  constexpr bool X3P = x3_pipelined(PRO, SMALLC, X3);
+  constexpr int MAIN_FLOATS = X3 ? x3_main_floats(BM, BN, X3P) : (GLDS ? (LOWF ? 1 : 2) * (BM + BN) * 32 : (BM + BN) * LDK);
   constexpr int EPI_FLOATS = (LOWF ? 2 : WM * WN) * 32 * CPITCH;
   constexpr int POST_FLOATS = HASPOST ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
   constexpr int LDS_FLOATS0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || WM * WN >= 8)) ? 1
     k_end = (int)((long long)(split + 1) * nsteps_all / nsplit);
   }
   int tapi = k_begin / nchunk, ci0 = (k_begin - tapi * nchunk) * BK;
-  if (k_begin < k_end && !GLDS) {
+  if (k_begin < k_end && !GLDS && !X3P) {
     if constexpr (!SMALLC && !X3) set_tap(tapi);
     gload(tapi, ci0);
   }
@@ -332,6 +339,133 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || WM * WN >= 8)) ? 1
   if (a.clk) { clk0 = __builtin_readcyclecounter(); wall0 = wall_clock64(); }
 #endif
 
+  // ---- X3P (bf16x3, PRO_NONE): software-pipelined K loop in 16-wide stages ----------------------------------------------------
+  // The single-stage loop (below; round 1) alternates "split + write LDS" and "read LDS + multiply" between two barriers per
+  // 32-wide K-step: while the operands of the next step are split (22 VALU instructions per 4 floats) the matrix pipe idles,
+  // and it ran at half of the bf16 MFMA rate (gs2.fwd 393 us for 150 us of MFMA work).  Here a stage is 16 k's -- exactly one
+  // v_mfma_f32_32x32x16_bf16 deep -- in unpadded 32-byte rows per plane (8 consecutive lanes x 16 bytes cover all 64 banks:
+  // conflict-free ds_read_b128), and there are TWO stages: while a wave's 6 x TM x TN MFMAs of stage s execute, the same
+  // wave splits the registers of stage s + 1 into the other LDS stage and requests stage s + 2 from global memory; one
+  // barrier per stage.  Same operands, same plane order, same k order per accumulator as the single-stage loop: bit-identical.
+  if constexpr (X3P) {
+    constexpr int ROWB = 32;                                   // bytes per row per plane per stage: 16 bf16
+    constexpr int A_PL = BM * ROWB, B_PL = BN * ROWB, STAGE_B = 3 * (A_PL + B_PL);
+    constexpr int PA2 = BM * 4 / NT;                           // 16-byte f32 pieces (4 k's) of the A stage per thread
+    static_assert((BM * 4) % NT == 0 && NT % 4 == 0, "x3 pipelined loader mismatch");
+    constexpr int NBP = BN * 6, PB2 = (NBP + NT - 1) / NT;     // 16-byte pieces of the pre-split weight stage (3 planes x 32 B per row)
+    char* const sm = reinterpret_cast<char*>(smem);
+    const int c4 = tid & 3, prow = tid >> 2;                   // piece (row prow + p * NT / 4, floats c4 * 4 .. + 3 of the stage)
+    int q_iy[PA2], q_ix[PA2], q_base[PA2];
+#pragma unroll
+    for (int p = 0; p < PA2; ++p) {
+      const int m = m0 + prow + p * (NT / 4);
+      if (m < Mtot) {
+        const int j = m % a.Wg;
+        const int t = m / a.Wg;
+        q_iy[p] = (t % a.Hg) * a.s_in; q_ix[p] = j * a.s_in; q_base[p] = (t / a.Hg) * a.Hin * a.Win;
+      } else {
+        q_iy[p] = -(1 << 20); q_ix[p] = 0; q_base[p] = 0;
+      }
+    }
+    long long q_off[PA2];
+    bool q_ok[PA2];
+    size_t w_off = 0;
+    auto tap2 = [&](int t) {
+      const ConvTap tp = a.taps[ph.tap_begin + t];
+#pragma unroll
+      for (int p = 0; p < PA2; ++p) {
+        const int iy = q_iy[p] + tp.dy, ix = q_ix[p] + tp.dx;
+        q_ok[p] = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        q_off[p] = (long long)((size_t)(q_base[p] + iy * a.Win + ix) * a.in_cs + a.in_coff + c4 * 4);
+      }
+      w_off = ((size_t)tp.slab * a.Npad + n0) * (size_t)(a.Cin / BK) * 96;
+    };
+    f32x4 qa[PA2];
+    u32x4 qb[PB2];
+    auto gload2 = [&](int ci) {                                // ci: first input channel of the stage (multiple of 16)
+#pragma unroll
+      for (int p = 0; p < PA2; ++p) qa[p] = q_ok[p] ? ld4(a.in + (size_t)(q_off[p] + ci)) : zero4;
+      const unsigned short* wb = a.w3 + w_off + (size_t)(ci >> 5) * 96 + ((ci >> 4) & 1) * 16;
+#pragma unroll
+      for (int k = 0; k < PB2; ++k) {
+        const int f = tid + NT * k;
+        const int nl = f / 6, r6 = f - nl * 6;                 // row nl: plane r6 >> 1, 16-byte half r6 & 1
+        if (NBP % NT == 0 || k + 1 < PB2 || f < NBP)
+          qb[k] = *reinterpret_cast<const u32x4*>(wb + (size_t)nl * (a.Cin / BK) * 96 + (r6 >> 1) * 32 + (r6 & 1) * 8);
+      }
+    };
+    auto stash = [&](int buf) {                                // split the staged activations, write both operands to stage `buf`
+      char* const st = sm + buf * STAGE_B;
+#pragma unroll
+      for (int p = 0; p < PA2; ++p) {
+        u32x2 h, m, l;
+        split3(qa[p], h, m, l);
+        char* dst = st + (prow + p * (NT / 4)) * ROWB + c4 * 8;
+        *reinterpret_cast<u32x2*>(dst) = h;
+        *reinterpret_cast<u32x2*>(dst + A_PL) = m;
+        *reinterpret_cast<u32x2*>(dst + 2 * A_PL) = l;
+      }
+#pragma unroll
+      for (int k = 0; k < PB2; ++k) {
+        const int f = tid + NT * k;
+        const int nl = f / 6, r6 = f - nl * 6;
+        if (NBP % NT == 0 || k + 1 < PB2 || f < NBP)
+          *reinterpret_cast<u32x4*>(st + 3 * A_PL + (r6 >> 1) * B_PL + nl * ROWB + (r6 & 1) * 16) = qb[k];
+      }
+    };
+    const int nchunk2 = a.Cin / 16;
+    const int s_begin = 2 * k_begin, s_end = 2 * k_end;
+    int tap_l = s_begin / nchunk2, ci_l = (s_begin - tap_l * nchunk2) * 16;      // the stage the loader is at
+    auto advance = [&]() {
+      ci_l += 16;
+      if (ci_l >= a.Cin) { ci_l = 0; ++tap_l; }
+    };
+    if (s_begin < s_end) {
+      tap2(tap_l);
+      gload2(ci_l);
+      stash(0);
+      advance();
+      if (s_begin + 1 < s_end) {
+        if (ci_l == 0) tap2(tap_l);
+        gload2(ci_l);
+      }
+    }
+    __syncthreads();
+    const int fa = arow * ROWB + (lane >> 5) * 16;
+    const int fb = 3 * A_PL + brow * ROWB + (lane >> 5) * 16;
+    for (int s2 = s_begin; s2 < s_end; ++s2) {
+      const int cur = (s2 - s_begin) & 1;
+      const char* const st = sm + cur * STAGE_B;
+      bf16x8 af3[3][TM], bf3[3][TN];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          af3[pl][tm] = *reinterpret_cast<const bf16x8*>(st + pl * A_PL + fa + tm * 32 * ROWB);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          bf3[pl][tn] = *reinterpret_cast<const bf16x8*>(st + pl * B_PL + fb + tn * 32 * ROWB);
+      }
+      if (s2 + 1 < s_end) {
+        stash(cur ^ 1);                                        // stage s2 + 1 (its registers were requested one stage ago)
+        advance();
+        if (s2 + 2 < s_end) {
+          if (ci_l == 0) tap2(tap_l);
+          gload2(ci_l);                                        // stage s2 + 2
+        }
+      }
+      constexpr int PA6[6] = {2, 0, 1, 1, 0, 0};               // A plane: l, h, m, m, h, h   (smallest products first)
+      constexpr int PB6[6] = {0, 2, 1, 0, 1, 0};               // B plane: h, l, m, h, m, h
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[PA6[c]][tm], bf3[PB6[c]][tn], acc[tm][tn], 0, 0, 0);
+      __syncthreads();
+    }
+  } else
   // ---- GLDS (f32 instances of glds_instance): operands by LDS-DMA ---------------------------------------------------------
   // `global_load_lds_dwordx4` moves 16 bytes per lane from global memory straight into LDS: no staging
   // registers, no ds_write, and with two LDS stages one barrier per K-step (the loads of step k+1 are issued at
@@ -918,7 +1052,8 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr bool GLDS = glds_instance(TM, TN, WM, WN, PRO, SMALLC, X3, POST);
   constexpr bool LOWF = POST == 3;
-  constexpr int MAIN_FLOATS = X3 ? 3 * (BM + BN) * X3_PITCH / 4 : (GLDS ? (LOWF ? 1 : 2) * (BM + BN) * 32 : (BM + BN) * LDK);
+  constexpr int MAIN_FLOATS = X3 ? x3_main_floats(BM, BN, x3_pipelined(PRO, SMALLC, X3))
+                                 : (GLDS ? (LOWF ? 1 : 2) * (BM + BN) * 32 : (BM + BN) * LDK);
   constexpr int EPI_FLOATS = (LOWF ? 2 : WM * WN) * 32 * (TN * 32 + 4);
   constexpr int POST_FLOATS = (POST == 1 || POST == 2) ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
   constexpr int F0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
@@ -987,6 +1122,7 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
     case 32: tn = 1; tm = 1; wm = 4; wn = 1; break;
   }
   if (a.bm == 256) wm = 4;
+  if (a.bm == 256 && a.x3 && a.x3w4 && !a.post) { wm = 2; tm = 4; }
   if (a.bm == 64) tm = 1;
   snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%s,%d>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
            a.smallc ? "true" : "false", (a.x3 && !a.smallc && bn != 32) ? "true" : "false",
@@ -1040,6 +1176,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
 #endif
           return launch_inst<2, 3, 4, 2, PRO_NONE, false, false, 1>(a, stream);
         }
+        if (a.x3 && a.x3w4) return launch_inst<4, 3, 2, 2, PRO_NONE, false, true>(a, stream);
         if (a.x3) return launch_inst<2, 3, 4, 2, PRO_NONE, false, true>(a, stream);
         return launch_inst<2, 3, 4, 2, PRO_NONE, false>(a, stream);
       }

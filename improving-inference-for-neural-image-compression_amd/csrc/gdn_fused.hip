@@ -123,15 +123,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
 
   // ---- prologue (b): g = 5x5/2 convolution of the zero-bordered 3-channel image ---------------
   if constexpr (PRO == GDN_PRO_CONV3) {
-    constexpr int PA = BM / RPP;
-    static_assert(BM % RPP == 0, "conv loader mismatch");
+    constexpr int PA = (BM + RPP - 1) / RPP;     // (32-row tile x 6 waves: one pass of the loader covers 48 rows, 32 are real)
+    constexpr bool PA_TAIL = BM % RPP != 0;
     float* As = Tt;                              // [BM][LDK], aliases the (not yet filled) tile
     int a_off[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
       const long long m = m0 + p * RPP + lrow;
       a_off[p] = -1;
-      if (m < a.M) {
+      if (m < a.M && (!PA_TAIL || p * RPP + lrow < BM)) {
         const int j = (int)(m % a.Wg);
         const long long t = m / a.Wg;
         const int i = (int)(t % a.Hg), b = (int)(t / a.Hg);
@@ -143,9 +143,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
     // epilogue registers are not live yet).  Step by step -- load, LDS, barrier, multiply -- the prologue was three
     // dependent round trips to L2: 11.1 us per workgroup for 3.9 us of MFMA work (in-kernel stamps,
     // profiles/r02_clock_probe.txt).
-    f32x4 ra[3][PA], rbs[3][PB];
-#pragma unroll
-    for (int step = 0; step < 3; ++step) {
+    // (the 32-row shape -- three workgroups per CU, 96 VGPRs -- takes the steps one at a time: its latency is hidden by the
+    // other resident workgroups, and 60 staging registers would cost it the third one)
+    constexpr int NS = PA_TAIL ? 1 : 3;
+    f32x4 ra[NS][PA], rbs[NS][PB];
+    auto load_step = [&](int step, int slot) {
       // one K-step = kernel rows (2*step, 2*step+1), 16 floats each (5 taps x 3 channels + 1 of slack
       // that meets a zero weight); row 5 does not exist: its weights are zero, re-read row 4
       int ky = 2 * step + (chunk >> 2);
@@ -155,17 +157,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
         const bool okp = a_off[p] >= 0;
         const float* src = a.pad + (size_t)(okp ? a_off[p] : 0) + (size_t)ky * a.Wp * 3 + (chunk & 3) * 4;
         const f32x2 lo = ld2(src), hi = ld2(src + 2);
-        ra[step][p] = okp ? f32x4{lo.x, lo.y, hi.x, hi.y} : f32x4{0.f, 0.f, 0.f, 0.f};
+        ra[slot][p] = okp ? f32x4{lo.x, lo.y, hi.x, hi.y} : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int p = 0; p < PB; ++p) rbs[step][p] = ld4(a.wc + (size_t)step * C * 32 + (size_t)(p * RPP + lrow) * 32 + chunk * 4);
+      for (int p = 0; p < PB; ++p) rbs[slot][p] = ld4(a.wc + (size_t)step * C * 32 + (size_t)(p * RPP + lrow) * 32 + chunk * 4);
+    };
+    if constexpr (NS == 3) {
+#pragma unroll
+      for (int step = 0; step < 3; ++step) load_step(step, step);
     }
 #pragma unroll
     for (int step = 0; step < 3; ++step) {
+      const int slot = NS == 3 ? step : 0;
+      if constexpr (NS == 1) load_step(step, 0);
 #pragma unroll
-      for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(&As[(p * RPP + lrow) * LDK + chunk * 4]) = ra[step][p];
+      for (int p = 0; p < PA; ++p)
+        if (!PA_TAIL || p * RPP + lrow < BM) *reinterpret_cast<f32x4*>(&As[(p * RPP + lrow) * LDK + chunk * 4]) = ra[slot][p];
 #pragma unroll
-      for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(&Bs[(p * RPP + lrow) * LDK + chunk * 4]) = rbs[step][p];
+      for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(&Bs[(p * RPP + lrow) * LDK + chunk * 4]) = rbs[slot][p];
       __syncthreads();
       mfma_step(As, LDK, 0);
       __syncthreads();
@@ -353,10 +362,7 @@ template <int NC, int WM, int WN>
 int launch_mode(const GdnArgs& a, hipStream_t s) {
   if (a.pro == GDN_PRO_CONV3) {
     if (a.mode != GDN_IGDN_BWD) return (int)hipErrorInvalidValue;
-    if constexpr (WM * 32 % (WM * WN * 8) == 0)
-      return launch_inst<NC, WM, WN, GDN_IGDN_BWD, GDN_PRO_CONV3>(a, s);
-    else
-      return (int)hipErrorInvalidValue;
+    return launch_inst<NC, WM, WN, GDN_IGDN_BWD, GDN_PRO_CONV3>(a, s);
   }
   switch (a.mode) {
     case GDN_IGDN_FWD: return launch_inst<NC, WM, WN, GDN_IGDN_FWD, GDN_PRO_LOAD>(a, s);
@@ -373,7 +379,7 @@ void pick_shape(int C, long long M, bool conv3, int& wm, int& wn) {
   if (nc == 8) { wm = 1; wn = 4; } else { wm = 2; wn = 2; }
   const long long tiles = (M + wm * 32 - 1) / (wm * 32);
   static const int force = [] { const char* e = LAB_ENV("SGA_GDN_SHAPE"); return e ? atoi(e) : 0; }();   // experiments
-  if (((tiles < 256 && force != 2) || force == 1) && !conv3) { wm = 1; wn = nc; }
+  if ((((tiles < 256 && force != 2) || force == 1) && !conv3) || force == 3) { wm = 1; wn = nc; }      // 3: also the conv3 prologue
 }
 
 }  // namespace

@@ -446,6 +446,8 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   // 177 us, 96 vs 88 us), so those launches stay on the f32 MFMA kernel (2.21 -> 2.30 img/s).
   a.x3 = (h->x3 && a.w3 && !a.smallc && a.epi != EPI_SHUFFLE3 && a.pro != PRO_IGDN_BWD &&
           a.Npad / a.ntiles_n != 96) ? 1 : 0;
+  { static const bool w4 = LAB_ENV("SGA_X3_W4") != nullptr && LAB_ENV("SGA_X3_W4")[0] == '1';
+    a.x3w4 = (w4 && a.x3 && a.bm == 256 && !a.post) ? 1 : 0; }
   const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
   if (a.ksplit > 1) { a.part = h->cur_part->p; a.slab = n_out; }
   bool gprof_here = false;

@@ -141,10 +141,14 @@ def _acceptance(gpu_out_dir, golden, precision, tag):
         assert abs(rep["mean_d_bpp_back"]) <= TOL_BPP, rep
     # per image (mean over the seeds): no systematic offset of any image beyond the tolerance (or 3.5 standard errors
     # of that image's mean when it has fewer than 16 seeds)
+    # (a per-image mean over k seeds carries a standard error of std / sqrt(k): where that is not small against the
+    # tolerance -- few seeds, or the trained-like sets whose single runs scatter by 0.04 dB -- the bound is 3.5 standard errors)
     k = d_bpp.shape[0]
-    img_tol = TOL_BPP if k >= 16 else np.maximum(TOL_BPP, 3.5 * d_bpp.std(0, ddof=1) / np.sqrt(k))
+    img_tol = np.maximum(TOL_BPP, 3.5 * d_bpp.std(0, ddof=1) / np.sqrt(k))
+    img_tol_p = np.maximum(TOL_PSNR, 3.5 * d_psnr.std(0, ddof=1) / np.sqrt(k))
+    rep["per_image_tol_bpp"], rep["per_image_tol_psnr"] = img_tol.tolist(), img_tol_p.tolist()
     assert (np.abs(d_bpp.mean(0)) <= img_tol).all(), rep
-    assert np.abs(d_psnr.mean(0)).max() <= TOL_PSNR, rep
+    assert (np.abs(d_psnr.mean(0)) <= img_tol_p).all(), rep
     # single runs stay inside the optimiser's own noise: 5 sigma of the seed-to-seed spread of a
     # difference of two draws (sqrt(2) sigma), and the HIP path's spread equals the oracle's
     sig_b = np.sqrt(2.0) * np.array(spread["est_bpp_std_per_image"])

@@ -110,3 +110,53 @@ def test_bits_back_coding_of_z_for_cfg5(gpu_out_dir):
     assert abs((info["z_bits"] - info["bits_back"]) - rep["est_z_minus_back_bits"]) < 0.08 * abs(info["z_bits"]) + 64, rep
     assert abs(info["net_bits"] / est_net - 1) < 0.08, rep
     codec.close()
+
+
+def test_bits_back_round_trip_at_kodak_size(gpu_out_dir):
+    """the bits-back coder at cfg 5's real size (C = 192, 512 x 768: z has 8 x 12 x 192 = 18 432 elements).
+    Sampling z_bar ~ Q by popping used the conditional's tables, whose escape symbol (frequency >= 1 / 65536) was hit about
+    once in four images of this size and then read 32 raw stack bits as the value (|z_bar| ~ 1e8 -> inf / NaN scales ->
+    the rate explodes).  With the posterior's own escape-free tables: every popped symbol is a regular one (|k - rint(mean
+    / delta)| <= 6 sigma + 1 of its table), the round trip is exact for several initial stacks, every borrowed bit comes
+    back, and the bits got back equal the ideal code length of the popped symbols under the quantised Q tables."""
+    import json, os
+    from sga_amd.codec import SGACodec
+    from sga_amd.bits_back import BitsBackCoder
+    C, B, H, W = 192, 1, 512, 768
+    w = sga_amd.make_synthetic_weights(C, seed=0, bb=True)
+    # the untrained h_a emits |mean|, |logvar| ~ 20 at this size: keep the posterior where a trained model puts it
+    # (tests/test_gpu_configs.py::test_bits_back_step_at_kodak_size does the same) by shrinking the last h_a layer
+    w["ha.k2"] = (w["ha.k2"] * np.float32(0.05)).astype(np.float32)
+    codec = SGACodec(w, C, B, H, W, bits_back=True)
+    x = np.random.RandomState(6).rand(B, H, W, 3).astype(np.float32)
+    kw = dict(r_its=25, r_lr=0.003, seed=4)
+    y_hat, zml, met, _, _ = codec.bb_run(x, 0.01, its=25, **kw)
+    assert torch.isfinite(zml).all()
+    bb = BitsBackCoder(codec, delta=1.0 / 8)
+    zm = zml.cpu().numpy()
+    r0q, tabq = bb._q_tables(zm)
+    assert r0q.size == 18432
+    rep = []
+    for seed in range(6):                                     # six different initial stacks = six different draws of z_bar
+        blob, info = bb.encode(y_hat, zml, seed=seed)
+        k = np.rint(info["z_bar"] / bb.delta).astype(np.int64)
+        sym = (k - r0q).reshape(-1)
+        assert bb.q.in_range(sym, tabq.reshape(-1)) and np.abs(sym).max() <= 1537, np.abs(sym).max()
+        # bits got back == ideal code length of the popped symbols under the quantised posterior tables (rANS: < 1 % + flush)
+        t = tabq.reshape(-1)
+        i = sym - bb.q.offs[t]
+        f = bb.q.cdf[t, i + 1].astype(np.float64) - bb.q.cdf[t, i]
+        ideal = float(-np.log2(f / 65536.0).sum())
+        assert abs(info["bits_back"] - ideal) < 0.01 * ideal + 64, (info["bits_back"], ideal)
+        y2, z_bar, rest, x_state = bb.decode(blob, H, W, **kw)
+        assert np.array_equal(y2, y_hat.cpu().numpy()) and np.array_equal(z_bar, info["z_bar"])
+        n_init = int(round((info["init_bits"] - 23.0) / 8))
+        assert rest == np.random.RandomState(seed).bytes(n_init) and x_state == 1 << 23
+        rep.append(dict(seed=seed, bits_back=info["bits_back"], ideal_back_bits=ideal, y_bits=info["y_bits"], z_bits=info["z_bits"],
+                        net_bits=info["net_bits"], max_abs_symbol=int(np.abs(sym).max())))
+    # the draws differ (the initial bits ARE the randomness) but their rates agree to a few per cent
+    net = np.array([r["net_bits"] for r in rep])
+    assert net.std() < 0.05 * abs(net.mean()), net
+    with open(os.path.join(gpu_out_dir, "parity_entropy.jsonl"), "a") as f:
+        f.write(json.dumps(dict(test="bits_back_kodak_size", runs=rep)) + "\n")
+    codec.close()
