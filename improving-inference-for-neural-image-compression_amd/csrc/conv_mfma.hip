@@ -1176,7 +1176,9 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
 #endif
           return launch_inst<2, 3, 4, 2, PRO_NONE, false, false, 1>(a, stream);
         }
+#ifdef SGA_EXPERIMENTS      // (one wave per SIMD, 128 x 96 per wave: gs2.bwd 343 us against 302 for the 8-wave instance; A.9)
         if (a.x3 && a.x3w4) return launch_inst<4, 3, 2, 2, PRO_NONE, false, true>(a, stream);
+#endif
         if (a.x3) return launch_inst<2, 3, 4, 2, PRO_NONE, false, true>(a, stream);
         return launch_inst<2, 3, 4, 2, PRO_NONE, false>(a, stream);
       }

@@ -38,7 +38,7 @@ TOL_BPP, TOL_PSNR = 1e-3, 0.01          # north_star tolerance
 @pytest.mark.parametrize("golden", ["full_run_oracle.json", "full_run_oracle_c192.json", "full_run_oracle_bb.json",
                                     "full_run_oracle_ragged.json", "full_run_oracle_hirate.json",
                                     "full_run_oracle_f64.json", "full_run_oracle_fitted.json",
-                                    "full_run_oracle_fitted_b011.json"])
+                                    "full_run_oracle_fitted_b011.json", "full_run_oracle_bb_fitted.json"])
 def test_full_run_matches_oracle_golden_within_north_star_tolerance(gpu_out_dir, golden):
     rep = _acceptance(gpu_out_dir, golden, "f32", "")
     assert rep["resolves_1e3_bpp"], rep          # these sets are large enough for the tolerance itself to be the bound

@@ -216,10 +216,37 @@ def test_base_compress_between_runs_leaves_the_step_graph_alone():
     y1, z1, m1 = codec.base_compress(x)                   # bound 0.11 for this call only
     assert codec.scale_bound == 0.0 and codec.fork_point() == fp
     b = codec.run(x, 0.01, its=120, seed=5)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    cols = [0, 1, 4, 5, 6]                                # (MS-SSIM is NaN below 176 x 176, as in TF)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2][:, cols], b[2][:, cols])
     built = SGACodec(w, C, B, H, W, scale_bound=0.11)
     y2, z2, m2 = built.base_compress(x)
     assert torch.equal(y1, y2) and torch.equal(z1, z2) and torch.equal(m1[:, [0, 1, 4, 5, 6]], m2[:, [0, 1, 4, 5, 6]])
     y3, z3, m3 = codec.base_compress(x, scale_bound=0.0)
     assert not torch.equal(m3[:, 4], m1[:, 4]) or float((m3[:, 4] - m1[:, 4]).abs().max()) == 0.0
     codec.close(); built.close()
+
+
+def test_bits_back_step_at_kodak_size_trained_like_weights(gpu_out_dir):
+    """cfg 5 at Kodak size WITHOUT touching the posterior: the bits-back model fitted by
+    tests/tools/fit_weights.py (C = 64; log-variances 0.5 .. 3.1) needs no clipping of (z_mean, z_logvar) and no scaled
+    h_a layer for exp() to stay finite -- one bits-back evaluation (bb_sga.py:93-158) vs the float64 oracle, raw sigma."""
+    from sga_amd.codec import SGACodec
+    C, H, W = 64, 512, 768
+    w = sga_amd.load_weights_npz(os.path.join(os.path.dirname(__file__), "golden", "fitted_weights_c64bb.npz"))
+    codec = SGACodec(w, C, 1, H, W, bits_back=True)
+    orc, orc64 = SGAOracle(w), SGAOracle(w, dtype=torch.float64)
+    x = sga_amd.make_lowpass_images(1, H, W, seed=31)
+    yo = orc.analysis(torch.tensor(x))
+    zml = orc.bb_init_z(yo.numpy()).numpy()
+    assert np.abs(zml).max() < 30 and np.isfinite(np.exp(0.5 * zml[..., C:])).all()
+    rng = np.random.RandomState(3)
+    u_y = rng.uniform(1e-4, 1 - 1e-4, (yo.numel(), 2)).astype(np.float32)
+    eps = rng.standard_normal(zml.size // 2).astype(np.float32)
+    ref = orc64.bb_step(x, yo.numpy(), zml, 0.35, u_y, eps, 0.01)
+    got = codec.bb_step_grads(x, yo.numpy(), zml, 0.35, 0.01, u_y=u_y, eps=eps)
+    ey = rel_err(got["gy"].cpu().numpy(), ref["gy"].numpy())
+    ez = rel_err(got["gzml"].cpu().numpy(), ref["gzml"].numpy())
+    report(gpu_out_dir, test="config_bb_step_fitted", H=H, W=W, gy=ey, gzml=ez, rd_loss=got["rd_loss"], rd_loss_ref=ref["rd_loss"])
+    assert ey < 1e-4 and ez < 2e-4, (ey, ez)
+    assert abs(got["rd_loss"] / ref["rd_loss"] - 1) < 1e-5
+    codec.close()

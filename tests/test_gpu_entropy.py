@@ -160,3 +160,36 @@ def test_bits_back_round_trip_at_kodak_size(gpu_out_dir):
     with open(os.path.join(gpu_out_dir, "parity_entropy.jsonl"), "a") as f:
         f.write(json.dumps(dict(test="bits_back_kodak_size", runs=rep)) + "\n")
     codec.close()
+
+
+def test_bits_back_rate_at_kodak_size_trained_like_weights(gpu_out_dir):
+    """The coder's NET size against the model's estimate (bb_sga.py:129-140: y_bpp + z_bpp - bpp_back) where the estimate
+    means something: the fitted bits-back model (tests/golden/fitted_weights_c64bb.npz) on a 512 x 768 low-pass image, a
+    short two-stage run, posterior untouched.  Exact round trip, and the coded net size within 8 % of the estimate
+    evaluated at the coded z_bar (table quantisation of p(y | z), the grid of width 1/8 for z)."""
+    import json, os
+    from sga_amd.codec import SGACodec, metrics_to_dict
+    from sga_amd.bits_back import BitsBackCoder
+    C, B, H, W = 64, 1, 512, 768
+    w = sga_amd.load_weights_npz(os.path.join(os.path.dirname(__file__), "golden", "fitted_weights_c64bb.npz"))
+    codec = SGACodec(w, C, B, H, W, bits_back=True)
+    x = sga_amd.make_lowpass_images(B, H, W, seed=33)
+    kw = dict(r_its=60, r_lr=0.003, seed=2)
+    y_hat, zml, met, _, _ = codec.bb_run(x, 0.01, its=60, **kw)
+    bb = BitsBackCoder(codec, delta=1.0 / 8)
+    blob, info = bb.encode(y_hat, zml, seed=5)
+    y2, z_bar, rest, x_state = bb.decode(blob, H, W, **kw)
+    assert np.array_equal(y2, y_hat.cpu().numpy()) and np.array_equal(z_bar, info["z_bar"]) and x_state == 1 << 23
+    zm = zml.cpu().numpy()
+    eps = (z_bar - zm[..., :C]) / np.exp(0.5 * zm[..., C:])
+    m = metrics_to_dict(codec.bb_evaluate(x, y_hat, zml, eps=eps.astype(np.float32)))
+    est_net = float(m["est_bpp"].sum()) * H * W
+    rep = dict(test="bits_back_rate_fitted", net_bits=info["net_bits"], est_net_bits=est_net, bits_back=info["bits_back"],
+               est_back_bits=float(m["est_bpp_back"].sum()) * H * W, y_bits=info["y_bits"], est_y_bits=float(m["est_y_bpp"].sum()) * H * W,
+               z_bits=info["z_bits"], est_z_bits=float(m["est_z_bpp"].sum()) * H * W, bpp_coded=info["net_bits"] / (H * W))
+    with open(os.path.join(gpu_out_dir, "parity_entropy.jsonl"), "a") as f:
+        f.write(json.dumps(rep) + "\n")
+    assert np.isfinite(est_net) and est_net > 0
+    assert abs(info["net_bits"] / est_net - 1) < 0.08, rep
+    assert abs(info["y_bits"] / rep["est_y_bits"] - 1) < 0.08, rep
+    codec.close()

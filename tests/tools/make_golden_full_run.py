@@ -61,6 +61,11 @@ CFGS = {
                    weights="fitted_c64", inputs="lowpass", seeds=list(range(32))),
     "fitted_b011": dict(C=64, B=4, H=64, W=64, its=2000, lmbda=0.01, x_seed=21, weight_seed=0, scale_bound=0.11,
                         weights="fitted_c64", inputs="lowpass", seeds=list(range(32))),
+    # cfg 5 at a trained-like operating point: the bits-back model fitted by tests/tools/fit_weights.py (4000 bb steps: posterior
+    # log-variances 0.5 .. 3.1, |z_mean| <= 10.5 -- no clipping of the posterior needed anywhere), raw sigma (bb_sga.py:121-124
+    # never builds the conditional layer either), both stages
+    "bb_fitted": dict(C=64, B=2, H=64, W=64, its=2000, r_its=2000, lmbda=0.01, x_seed=23, weight_seed=0, bb=True, scale_bound=0.0,
+                      weights="fitted_c64bb", inputs="lowpass", seeds=list(range(32))),
     # CONTROL for the statistical criterion: the small set's inputs and Philox seeds through the float64 oracle.  The
     # float32-vs-float64 ORACLE difference is what "a different rounding of the same arithmetic" does to a 2000-step run;
     # tests/test_oracle.py asserts it has the spread the GPU acceptance test tolerates
