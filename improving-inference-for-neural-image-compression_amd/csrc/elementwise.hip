@@ -620,11 +620,26 @@ __global__ void k_check_iter(const StepCtx* __restrict__ ctx, int expected_it, i
 __global__ void k_fence() { __threadfence_system(); }
 
 // debug (SGA_DEBUG_DUMP): order-independent 64-bit checksum of a float buffer
-__global__ void k_checksum(const unsigned* __restrict__ p, int64_t n, unsigned long long* out) {
+// ctx != null: the slot row is chosen ON THE DEVICE -- out + (ctx->it - 1) * 16 (the context was already advanced by the
+// iteration's finalize) -- so that the launch can live in a replayed graph
+__global__ void k_checksum(const unsigned* __restrict__ p, int64_t n, unsigned long long* out, const StepCtx* __restrict__ ctx) {
+  if (ctx) out += (size_t)(ctx->it > 0 ? ctx->it - 1 : 0) * 16;
   unsigned long long acc = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     acc += (unsigned long long)p[i] * (2654435761ull * (unsigned long long)(i + 1) + 0x9E3779B97F4A7C15ull);
   atomicAdd(out, acc);
+}
+
+// debug (SGA_DEBUG_DUMP, A.8): ordering probe.  k_mark (main chain, right after the relaxation kernel) stores the wall clock in
+// slot 15 of the iteration's row; k_probe (FIRST kernel of the hyper branch) copies what it sees there into slot 14 and its own
+// wall clock into slot 13: a branch kernel that ran before its fork dependency sees 0 (the row is zeroed at run begin).
+__global__ void k_mark(unsigned long long* out, const StepCtx* __restrict__ ctx) {
+  out[(size_t)ctx->it * 16 + 15] = wall_clock64();
+}
+__global__ void k_probe(unsigned long long* out, const StepCtx* __restrict__ ctx) {
+  const size_t row = (size_t)ctx->it * 16;
+  out[row + 14] = __hip_atomic_load(&out[row + 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  out[row + 13] = wall_clock64();
 }
 
 // debug: hold a stream for `ticks` of the 100 MHz wall clock (SGA_DEBUG_DELAY_US)
@@ -984,8 +999,16 @@ int launch_fence(hipStream_t s) {
   hipLaunchKernelGGL(k_fence, dim3(64), dim3(64), 0, s);   // >= 1 workgroup per XCD (8 XCDs, round-robin)
   LAUNCH_RET();
 }
-int launch_checksum(const float* p, int64_t n, unsigned long long* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_checksum, dim3(grid_for(n, 256, 256)), dim3(256), 0, s, (const unsigned*)p, n, out);
+int launch_checksum(const float* p, int64_t n, unsigned long long* out, hipStream_t s, const StepCtx* ctx) {
+  hipLaunchKernelGGL(k_checksum, dim3(grid_for(n, 256, 256)), dim3(256), 0, s, (const unsigned*)p, n, out, ctx);
+  LAUNCH_RET();
+}
+int launch_mark(unsigned long long* out, const StepCtx* ctx, hipStream_t s) {
+  hipLaunchKernelGGL(k_mark, dim3(1), dim3(1), 0, s, out, ctx);
+  LAUNCH_RET();
+}
+int launch_probe(unsigned long long* out, const StepCtx* ctx, hipStream_t s) {
+  hipLaunchKernelGGL(k_probe, dim3(1), dim3(1), 0, s, out, ctx);
   LAUNCH_RET();
 }
 int launch_spin(int us, hipStream_t s) {

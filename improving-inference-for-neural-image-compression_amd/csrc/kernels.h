@@ -110,8 +110,10 @@ int launch_round_median(const float* z, const float* med, int64_t n, int C, floa
 int launch_fill(float* p, float val, int64_t n, hipStream_t s);
 int launch_check_iter(const StepCtx* ctx, int expected_it, int* bad, hipStream_t s);
 int launch_fence(hipStream_t s);
-int launch_checksum(const float* p, int64_t n, unsigned long long* out, hipStream_t s);
+int launch_checksum(const float* p, int64_t n, unsigned long long* out, hipStream_t s, const StepCtx* ctx = nullptr);
 int launch_spin(int us, hipStream_t s);
+int launch_mark(unsigned long long* out, const StepCtx* ctx, hipStream_t s);
+int launch_probe(unsigned long long* out, const StepCtx* ctx, hipStream_t s);
 int launch_set_int(int* p, int v, hipStream_t s);
 int launch_check_int(const int* p, int expected, int* bad, hipStream_t s);
 int launch_copy(float* dst, const float* src, int64_t n, hipStream_t s);

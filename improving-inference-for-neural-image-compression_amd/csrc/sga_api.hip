@@ -112,6 +112,7 @@ struct sga_handle {
   hipStream_t sB = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;           // eager launches
   const char* dump_path = nullptr; unsigned long long* dump = nullptr; int dump_run = 0;   // SGA_DEBUG_DUMP
+  bool dump_probe = false;         // SGA_DEBUG_PROBE=1: ordering probe kernels (k_mark / k_probe) with the dump
   int run_B = 0, run_H = 0, run_W = 0, run_its = -1, run_it = 0;   // sga_run_begin/steps state
   float run_lambda = 0.f, run_loss_scale = 1.f; uint64_t run_seed = 0;
   bool split256 = true;            // split-K also for a single-phase launch of exactly 256 tiles (SGA_SPLIT256=0: off)
@@ -446,6 +447,9 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   // 177 us, 96 vs 88 us), so those launches stay on the f32 MFMA kernel (2.21 -> 2.30 img/s).
   a.x3 = (h->x3 && a.w3 && !a.smallc && a.epi != EPI_SHUFFLE3 && a.pro != PRO_IGDN_BWD &&
           a.Npad / a.ntiles_n != 96) ? 1 : 0;
+  { // laboratory (A.8): bf16x3 arithmetic in only one of the two branches, to isolate the two-stream nondeterminism
+    static const int only = LAB_ENV("SGA_X3_ONLY") ? atoi(LAB_ENV("SGA_X3_ONLY")) : 0;      // 1: main chain only, 2: hyper branch only
+    if ((only == 1 && h->in_hyper) || (only == 2 && !h->in_hyper)) a.x3 = 0; }
   { static const bool w4 = LAB_ENV("SGA_X3_W4") != nullptr && LAB_ENV("SGA_X3_W4")[0] == '1';
     a.x3w4 = (w4 && a.x3 && a.bm == 256 && !a.post) ? 1 : 0; }
   const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
@@ -1026,6 +1030,7 @@ int hyper_branch_impl(sga_handle* h, const Geom& g, bool with_grad, hipStream_t 
   if (part != 2) {
   // experiment (SGA_FORK_DELAY_US): hold the branch back for a fixed time after its fork point -- a fork "inside" a launch
   if (h->fork_delay_us > 0 && st == h->sB) HIPCHK(h, launch_spin(h->fork_delay_us, st));
+  if (h->dump && h->dump_probe && with_grad) HIPCHK(h, launch_probe(h->dump, h->ctx, st));
   if (density)   // bits-back: prior DENSITY (bb_sga.py:105-106)
     HIPCHK(h, launch_factorized_pdf(h->zt.p, h->eb_packed, h->ctx, B, g.zh * g.zw, C, il, h->sums,
                                     with_grad ? h->g_zt_eb.p : nullptr, nullptr, nullptr, st));
@@ -1260,6 +1265,7 @@ int sga_step_core(sga_handle* h, const Geom& g, const float* x, const float* y, 
   if (!u_y && !u_z) {
     HIPCHK(h, launch_sample_yz(y, h->yt.p, h->dyt.p, ny, z, h->zt.p, h->dzt.p, nz, h->ctx, h->relax, h->img_ids,
                                g.B, st));
+    if (h->dump && h->dump_probe) HIPCHK(h, launch_mark(h->dump, h->ctx, st));
   } else {
     HIPCHK(h, launch_sample(z, u_z, h->ctx, 1, h->zt.p, h->dzt.p, nz, st, h->relax, h->img_ids, nz / g.B));
     HIPCHK(h, launch_sample(y, u_y, h->ctx, 0, h->yt.p, h->dyt.p, ny, st, h->relax, h->img_ids, ny / g.B));
@@ -1649,6 +1655,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     void* p = nullptr;
     if (dev_alloc(h, &p, (size_t)kMaxIts * 16 * 8) != SGA_OK) return fail(SGA_ERR_NOMEM);
     h->dump = (unsigned long long*)p;
+    h->dump_probe = LAB_ENV("SGA_DEBUG_PROBE") != nullptr;
   }
   env = getenv("SGA_X3_FORK");
   h->x3_fork = !(env && env[0] == '0');
@@ -1916,12 +1923,15 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
     HIPCHK(h, launch_adam_latent_yz(h->y.p, h->g_yt_dist.p, h->g_yt_rate.p, h->dyt.p, h->my.p, h->vy.p, ny,
                                     h->z.p, h->g_zt_hs.p, h->g_zt_eb.p, h->dzt.p, h->mz.p, h->vz.p, nz, h->ctx, s));
     HIPCHK(h, launch_finalize_step(h->sums, h->ctx, B, H, W, nullptr, nullptr, h->trace.p, s, h->Ttab.p, h->lrtab.p));
-    if (h->dump && h->dbg_it >= 0) {
-      unsigned long long* o = h->dump + (size_t)h->dbg_it * 16;
-      const float* bufs[12] = {h->yt.p, h->zt.p, h->u[0].p, h->v[0].p, h->u[1].p, h->u[2].p, h->g_yt_dist.p,
-                               h->g_yt_rate.p, h->g_zt_hs.p, h->g_zt_eb.p, h->y.p, h->z.p};
-      const int64_t ns[12] = {ny, nz, ny * 4, ny * 4, ny * 16, ny * 64, ny, ny, nz, nz, ny, nz};
-      for (int k = 0; k < 12; ++k) HIPCHK(h, launch_checksum(bufs[k], ns[k], o + k, s));
+    if (h->dump) {      // (laboratory, SGA_DEBUG_DUMP: per-iteration checksums of the step's buffers; the row is chosen on the device,
+                        //  so the launches replay with the graph)
+      const size_t B_ = (size_t)B;
+      const int64_t n_ms = (int64_t)B_ * g.hsh * g.hsw * 2 * C, n_hs1 = (int64_t)B_ * g.hsh * g.hsw * h->C15,
+                    n_hs0 = (int64_t)B_ * (2 * g.zh) * (2 * g.zw) * C;
+      const float* bufs[16] = {h->yt.p, h->zt.p, h->g_yt_dist.p, h->g_yt_rate.p, h->g_zt_hs.p, h->g_zt_eb.p, h->ms.p, h->g_ms.p,
+                               h->hs1.p, h->g_hs1.p, h->hs0.p, h->g_hs0.p, h->y.p, h->z.p, h->v[2].p, h->gB.p};
+      const int64_t ns[16] = {ny, nz, ny, ny, nz, nz, n_ms, n_ms, n_hs1, n_hs1, n_hs0, n_hs0, ny, nz, ny * 64, ny * 4};
+      for (int k = 0; k < (h->dump_probe ? 13 : 16); ++k) HIPCHK(h, launch_checksum(bufs[k], ns[k], h->dump + k, s, h->ctx));
     }
     return SGA_OK;
   };
@@ -2041,8 +2051,19 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(host.data(), h->dump, host.size() * 8, hipMemcpyDeviceToHost);
     char fn[512];
-    snprintf(fn, sizeof(fn), "%s.%d", h->dump_path, h->dump_run++);
+    snprintf(fn, sizeof(fn), "%s.%d", h->dump_path, h->dump_run);
     if (FILE* f = fopen(fn, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+    if (LAB_ENV("SGA_DEBUG_DUMP_BUFS")) {      // raw z_tilde, its rate gradient and the Jacobian as the last iteration left them
+      const float* bufs[3] = {h->zt.p, h->g_zt_eb.p, h->g_zt_hs.p};
+      const char* tags[3] = {"zt", "gzeb", "gzhs"};
+      std::vector<float> hb((size_t)nz);
+      for (int k = 0; k < 3; ++k) {
+        (void)hipMemcpy(hb.data(), bufs[k], hb.size() * 4, hipMemcpyDeviceToHost);
+        snprintf(fn, sizeof(fn), "%s.%s.%d", h->dump_path, tags[k], h->dump_run);
+        if (FILE* f = fopen(fn, "wb")) { fwrite(hb.data(), 4, hb.size(), f); fclose(f); }
+      }
+    }
+    h->dump_run++;
   }
   return SGA_OK;
 }

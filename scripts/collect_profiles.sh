@@ -2,7 +2,7 @@
 # GPU box: the measurement set committed under profiles/ (run from the repo root: bash scripts/collect_profiles.sh r03 <commit>)
 # Order: the PMC passes first, then the benchmark line and the roofline leg, so that bench.py finds THIS run's
 # rNN_pmc_traffic.json (copied into profiles/ right away) and one commit id appears in every file of the set.
-R=${1:-r03}; COMMIT=${2:-unknown}
+R=${1:-r04}; COMMIT=${2:-unknown}
 export TMPDIR=/tmp
 ROOT=$(pwd); O=$ROOT/gpurun_out/$R; mkdir -p $O
 # -- HBM traffic per kernel symbol: eager roofline leg with the hyper branch on its second stream (as in the run) and
@@ -20,9 +20,17 @@ python scripts/profile_layers.py > $O/layers_hipevents.txt 2>&1
 python scripts/perf_configs.py f32 > $O/configs.txt 2>&1
 # -- rocprofv3 kernel stats of the roofline leg (eager) and of the graph replay that the headline times
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_roofline -- python $ROOT/bench.py --roofline-only > $O/roofline_leg.json 2>/dev/null )
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_graph -- python $ROOT/bench.py --its 200 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-profile --no-other-input > $O/graph_its200.json 2>/dev/null )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_graph -- python $ROOT/bench.py --its 200 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-profile --no-other-input --no-alt-precision --no-other-configs > $O/graph_its200.json 2>/dev/null )
 cp $O/prof_roofline/*/*kernel_stats.csv $O/roofline_leg_kernel_stats.csv
 python scripts/timeline_from_trace.py $(ls $O/prof_graph/*/*kernel_trace.csv) 100 > $O/timeline_iteration.txt 2>&1
 cp $O/prof_graph/*/*kernel_stats.csv $O/graph_its200_kernel_stats.csv
+# -- the secondary precision mode (bf16x3, bench.py's `alt_precision`): layers, configs, kernel stats + timeline of the graph replay
+PREC=bf16x3 python scripts/profile_layers.py > $O/layers_hipevents_bf16x3.txt 2>&1
+python scripts/perf_configs.py bf16x3 > $O/configs_bf16x3.txt 2>&1
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_graph_x3 -- python $ROOT/bench.py --precision bf16x3 --its 200 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-profile --no-other-input --no-alt-precision --no-other-configs > $O/graph_its200_bf16x3.json 2>/dev/null )
+python scripts/timeline_from_trace.py $(ls $O/prof_graph_x3/*/*kernel_trace.csv) 100 > $O/timeline_iteration_bf16x3.txt 2>&1
+cp $O/prof_graph_x3/*/*kernel_stats.csv $O/graph_its200_bf16x3_kernel_stats.csv
+B=1 python scripts/profile_layers.py > $O/layers_hipevents_b1.txt 2>&1
+rm -rf $O/prof_graph_x3
 rm -rf $O/pmc_f $O/pmc_w $O/pmc_f1 $O/pmc_w1 $O/pmc_kernels/sq $O/pmc_kernels/lds $O/pmc_kernels/fetch $O/pmc_kernels/write
 ls $O

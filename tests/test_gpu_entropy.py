@@ -193,3 +193,25 @@ def test_bits_back_rate_at_kodak_size_trained_like_weights(gpu_out_dir):
     assert abs(info["net_bits"] / est_net - 1) < 0.08, rep
     assert abs(info["y_bits"] / rep["est_y_bits"] - 1) < 0.08, rep
     codec.close()
+
+
+def test_rans_oracle_decodes_the_device_stream():
+    """the device coder (csrc/rans.hip) checked by something that is not the product -- oracle/rans_ref.py
+    (the published rANS recurrences in Python integers) decodes the stream the DEVICE wrote for the (y_hat, mu, sigma) of a
+    short real run, escapes included, and re-encodes the symbols to the same bytes."""
+    from oracle import rans_ref
+    codec = _codec(64, 2, 64, 80)
+    coder = codec._entropy_coder()
+    x = np.random.RandomState(4).rand(2, 64, 80, 3).astype(np.float32)
+    y_hat, z_hat, _, _ = codec.run(x, 0.01, its=20, seed=1)
+    y_hat[0, 0, 0, :3] = torch.tensor([5000.0, -5000.0, 70000.0])          # escapes
+    yh, yw = y_hat.shape[1:3]
+    mu, sigma = codec.hyper_synthesis(z_hat, yh, yw)
+    ys = codec._ec_symbols_device(coder, y_hat, mu, sigma, None)
+    data = codec._ec_encode_device(coder, ys["y_sym"], ys["y_tab"])
+    bb, block, payload = ec.unframe_blocks(data)
+    sym, tab = ys["y_sym"].cpu().numpy().tolist(), ys["y_tab"].cpu().numpy().tolist()
+    assert rans_ref.decode_blocked(payload, bb.tolist(), tab, block, coder.cdf, coder.lens, coder.offs) == sym
+    sizes, ref_payload = rans_ref.encode_blocked(sym, tab, block, coder.cdf, coder.lens, coder.offs)
+    assert sizes == bb.tolist() and ref_payload == payload
+    codec.close()
