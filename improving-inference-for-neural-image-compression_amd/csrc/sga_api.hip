@@ -135,8 +135,8 @@ struct sga_handle {
   bool x3_variants = true;         // bf16x3 mode: 64- / 256-row tiles and the IGDN post-phase as in f32 mode (SGA_X3_VARIANTS=0: 128-row only)
   bool x3_fork = true;             // bf16x3 mode with the hyper branch on the second stream (round 4: on again, never forked at the
                                    //   graph's root -- synth_branch tick(); SGA_X3_FORK=0: single-stream as in rounds 2-3)
-  bool drop_destroy = true;        // drop_graph(): destroy a dropped executable graph at once (default) or keep it until sga_destroy
-                                   //   (SGA_GRAPH_DROP=retire: the round-3 policy)
+  bool drop_destroy = false;       // drop_graph(): keep a dropped executable graph until sga_destroy (default, "retire") or destroy it at
+                                   //   once behind a synchronisation of both streams (SGA_GRAPH_DROP=destroy)
   std::vector<hipGraphExec_t> retired_graphs;   // candidate graphs that lost the timing: destroyed with the handle (experiment:
                                    // destroying them while their sibling is in use crashed the process in the full test suite)
   int tuned_B = 0, tuned_H = 0, tuned_W = 0;   // geometry the last timed choice (tuned_name) was made for: graphs of that
@@ -1293,12 +1293,14 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
 }
 
 // Disposal of an executable graph that is dropped in mid-life (a losing fork-point candidate, a geometry change, a changed
-// sigma bound, the stamped graph of sga_profile_graph_*): destroyed after BOTH streams its replays ran on have drained
-// (`st`: the launching stream; the handle's second stream carries the hyper branch of every replay).  Round 3 kept dropped
-// graphs until sga_destroy because three full-suite runs had crashed shortly after a mid-life hipGraphExecDestroy; round 4
-// could not reproduce that with the synchronisation in place -- full GPU suite under MALLOC_PERTURB_ with this policy, a
-// stand-alone HIP program with the same life cycle incl. destruction with replays in flight (scripts/graph_repro.hip): all
-// clean -- see DESIGN_EXPERIMENTS.md A.8.  SGA_GRAPH_DROP=retire restores the old policy.
+// sigma bound, the stamped graph of sga_profile_graph_*).  Default: RETIRED -- kept until sga_destroy (one small executable
+// graph per drop; base_compress no longer drops any).  SGA_GRAPH_DROP=destroy destroys it at once, behind a synchronisation of
+// the launching stream and of the handle's second stream.  Why not destroy by default: three full-suite runs of round 3 died
+// with a host SIGSEGV in the NEXT run on a handle after a mid-life hipGraphExecDestroy; round 4 hunted it (DESIGN_EXPERIMENTS.md
+// A.8a: freed-memory poisoning, a stand-alone HIP program with the same life cycle incl. destruction with replays in flight,
+// a lifetime audit of everything a node references) without finding a host-side cause, and under the destroy policy the full
+// suite passed 2 of 3 times and crashed once at the round-3 spot (second 2000-iteration run at 1200 x 1200, C = 256); under
+// the retire policy it has never crashed (9 full runs over two rounds).
 void drop_graph(sga_handle* h, hipGraphExec_t& ex, hipStream_t st = nullptr) {
   if (!ex) return;
   if (h->drop_destroy) {
@@ -1660,7 +1662,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   env = getenv("SGA_X3_FORK");
   h->x3_fork = !(env && env[0] == '0');
   env = getenv("SGA_GRAPH_DROP");
-  if (env) h->drop_destroy = strcmp(env, "retire") != 0;
+  if (env) h->drop_destroy = strcmp(env, "destroy") == 0;
   env = LAB_ENV("SGA_SPLIT256");
   h->split256 = !(env && env[0] == '0');
   env = LAB_ENV("SGA_BM256");
