@@ -746,10 +746,36 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
       for (int p = 0; p < QB; ++p)
         *reinterpret_cast<f32x4*>(&Bq[buf * (C * LDK) + (p * RPP + lrow) * LDK + chunk * 4]) = rq[p];
     };
+    // bf16x3 form of the contraction (X3 instances): n = gamma . u^2 on v_mfma_f32_32x32x16_bf16 in 16-wide stages -- u^2 is
+    // split into its three bf16 planes as the fragments leave the tile (8 floats per lane and stage), gamma comes pre-split
+    // (a.post_wx3, the planes sga_create packs for every weight) through the gamma buffers as [plane][C][32 bytes]
+    constexpr int QSTG = 3 * C * 32;                 // bytes per staged gamma stage (three planes x C rows x 16 bf16)
+    constexpr int NQX = X3 ? (C * 6 + NT - 1) / NT : 1;
+    u32x4 qx[NQX];
+    char* const Bqb = reinterpret_cast<char*>(Bq);
+    auto load_qx = [&](int st) {                     // stage st = k's [16 st, 16 st + 16)
+      const unsigned short* wx = a.post_wx3 + (size_t)(st >> 1) * 96 + (st & 1) * 16;
+#pragma unroll
+      for (int k = 0; k < NQX; ++k) {
+        const int f = tid + NT * k;
+        const int nl = f / 6, r6 = f - nl * 6;
+        if ((C * 6) % NT == 0 || k + 1 < NQX || f < C * 6)
+          qx[k] = *reinterpret_cast<const u32x4*>(wx + (size_t)nl * (C / 32) * 96 + (r6 >> 1) * 32 + (r6 & 1) * 8);
+      }
+    };
+    auto store_qx = [&](int buf) {
+#pragma unroll
+      for (int k = 0; k < NQX; ++k) {
+        const int f = tid + NT * k;
+        const int nl = f / 6, r6 = f - nl * 6;
+        if ((C * 6) % NT == 0 || k + 1 < NQX || f < C * 6)
+          *reinterpret_cast<u32x4*>(Bqb + buf * QSTG + (r6 >> 1) * (C * 32) + nl * 32 + (r6 & 1) * 16) = qx[k];
+      }
+    };
     lds_barrier();                                   // main-loop LDS is dead from here on
 #pragma unroll
     for (int h = 0; h < NPART; ++h) {
-      load_q(0);
+      if constexpr (X3) load_qx(0); else load_q(0);
       if (wm / OW == h) {                            // the waves that own these HR rows: u = acc + bias
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -760,14 +786,52 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
               Tt[((wm % OW) * WR + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * TP + (wn * TN + tn) * 32 + col] =
                   acc[tm][tn][reg] + bias_c[tn];
       }
-      store_q(0);
-      load_q(1);
+      if constexpr (X3) { store_qx(0); load_qx(1); } else { store_q(0); load_q(1); }
       lds_barrier();
       f32x16 acc2[PTN];
 #pragma unroll
       for (int tn = 0; tn < PTN; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[tn][r] = 0.f;
+      if constexpr (X3) {
+        constexpr int NSTG = C / 16;
+#pragma unroll 2
+        for (int st = 0; st < NSTG; ++st) {
+          if constexpr (QBUF == 2) {
+            if (st + 1 < NSTG) store_qx((st + 1) & 1);
+            if (st + 2 < NSTG) load_qx(st + 2);
+          } else if (st > 0) {                       // one buffer: stage st replaces stage st - 1 between two barriers
+            store_qx(0);
+            if (st + 1 < NSTG) load_qx(st + 1);
+            lds_barrier();
+          }
+          const char* Bs3 = Bqb + (QBUF == 2 ? (st & 1) : 0) * QSTG;
+          const float* ap = &Tt[(m4 * 32 + col) * TP + st * 16 + half * 8];
+          f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
+          a0 = a0 * a0; a1 = a1 * a1;
+          u32x2 h0, m0, l0, h1, m1, l1;
+          split3(a0, h0, m0, l0);
+          split3(a1, h1, m1, l1);
+          bf16x8 ax[3];
+          ax[0] = __builtin_bit_cast(bf16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
+          ax[1] = __builtin_bit_cast(bf16x8, u32x4{m0.x, m0.y, m1.x, m1.y});
+          ax[2] = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
+          bf16x8 bx[3][PTN];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int tn = 0; tn < PTN; ++tn)
+              bx[pl][tn] = *reinterpret_cast<const bf16x8*>(Bs3 + pl * (C * 32) + ((n2 * PTN + tn) * 32 + col) * 32 + half * 16);
+          constexpr int PA6[6] = {2, 0, 1, 1, 0, 0};   // A plane: l, h, m, m, h, h   (smallest products first)
+          constexpr int PB6[6] = {0, 2, 1, 0, 1, 0};   // B plane: h, l, m, h, m, h
+#pragma unroll
+          for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int tn = 0; tn < PTN; ++tn)
+              acc2[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[PA6[c]], bx[PB6[c]][tn], acc2[tn], 0, 0, 0);
+          lds_barrier();
+        }
+      } else {
 #pragma unroll
       for (int kc = 0; kc < C / 32; ++kc) {
         if constexpr (QBUF == 2) {
@@ -794,6 +858,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
               acc2[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r], bf2[tn][r], acc2[tn], 0, 0, 0);
         }
         lds_barrier();
+      }
       }
       // ---- epilogue of the part: this wave's private 32 x (PTN * 32) block of the tile ---------------
       float* const cb = Tt + (m4 * 32 + 4 * half) * TP + n2 * PTN * 32 + col;     // C-layout base

@@ -28,15 +28,36 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// exact split of 4 floats into three planes of 4 packed bf16 (conv_mfma.hip: precision mode bf16x3)
+__device__ __forceinline__ unsigned gcvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ void gsplit3(const f32x4 v, u32x2& h, u32x2& m, u32x2& l) {
+  h.x = gcvt_pk_bf16(v.x, v.y);
+  h.y = gcvt_pk_bf16(v.z, v.w);
+  const float r0 = v.x - __uint_as_float(h.x << 16), r1 = v.y - __uint_as_float(h.x & 0xffff0000u);
+  const float r2 = v.z - __uint_as_float(h.y << 16), r3 = v.w - __uint_as_float(h.y & 0xffff0000u);
+  m.x = gcvt_pk_bf16(r0, r1);
+  m.y = gcvt_pk_bf16(r2, r3);
+  l.x = gcvt_pk_bf16(r0 - __uint_as_float(m.x << 16), r1 - __uint_as_float(m.x & 0xffff0000u));
+  l.y = gcvt_pk_bf16(r2 - __uint_as_float(m.y << 16), r3 - __uint_as_float(m.y & 0xffff0000u));
+}
+
 
 constexpr int LDK = 36;
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
 
-template <int NC, int WM, int WN, int MODE, int PRO>
+template <int NC, int WM, int WN, int MODE, int PRO, bool X3 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs a) {
   constexpr int C = NC * 32, NT = WM * WN * 64, BM = WM * 32, TN = NC / WN;
   constexpr int TP = C + 4;                      // tile pitch (floats)
@@ -186,7 +207,31 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
   GDN_STAMP(1);
   // first K-step of gamma: in flight during the fill (backward: after it -- its three input streams
   // leave no registers for it)
-  if constexpr (MODE != GDN_IGDN_BWD) load_b(gw, C, 0);
+  // (bf16x3 form of the contraction, X3: gamma comes pre-split into its bf16 planes -- a.wx3, the planes sga_create packs
+  //  for every weight -- one 16-wide stage at a time as [plane][C][32 bytes]; see the contraction below)
+  constexpr int NBX = X3 ? (C * 6 + NT - 1) / NT : 1;
+  u32x4 bxr[NBX];
+  char* const Bsb = reinterpret_cast<char*>(Bs);
+  auto load_bx = [&](int st) {
+    const unsigned short* wx = a.wx3 + (size_t)(st >> 1) * 96 + (st & 1) * 16;
+#pragma unroll
+    for (int k = 0; k < NBX; ++k) {
+      const int f = tid + NT * k;
+      const int nl = f / 6, r6 = f - nl * 6;
+      if ((C * 6) % NT == 0 || k + 1 < NBX || f < C * 6)
+        bxr[k] = *reinterpret_cast<const u32x4*>(wx + (size_t)nl * (C / 32) * 96 + (r6 >> 1) * 32 + (r6 & 1) * 8);
+    }
+  };
+  auto store_bx = [&]() {
+#pragma unroll
+    for (int k = 0; k < NBX; ++k) {
+      const int f = tid + NT * k;
+      const int nl = f / 6, r6 = f - nl * 6;
+      if ((C * 6) % NT == 0 || k + 1 < NBX || f < C * 6)
+        *reinterpret_cast<u32x4*>(Bsb + (r6 >> 1) * (C * 32) + nl * 32 + (r6 & 1) * 16) = bxr[k];
+    }
+  };
+  if constexpr (MODE != GDN_IGDN_BWD) { if constexpr (X3) load_bx(0); else load_b(gw, C, 0); }
 
   // ---- fill: one coalesced pass over the tile's inputs ----------------------------------------
   // All loads are unconditional (rows past M re-read row m0 and are discarded by a select) and issued
@@ -289,8 +334,40 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
 
   GDN_STAMP(2);
   // ---- C x C contraction with gamma, A resident in the tile ------------------------------------
-  if constexpr (MODE == GDN_IGDN_BWD) load_b(gw, C, 0);
+  if constexpr (MODE == GDN_IGDN_BWD) { if constexpr (X3) load_bx(0); else load_b(gw, C, 0); }
   zero_acc();
+  if constexpr (X3) {
+    // 16-wide stages on v_mfma_f32_32x32x16_bf16: the resident f32 operand is split into its three bf16 planes as the
+    // fragments leave the tile (8 floats per lane and stage); six plane products per stage, smallest first (conv_mfma.hip)
+#pragma unroll 1
+    for (int st = 0; st < C / 16; ++st) {
+      store_bx();
+      __syncthreads();                           // (st = 0: also publishes the tile)
+      if (st + 1 < C / 16) load_bx(st + 1);
+      const float* ap = &Tt[(wm * 32 + col) * TP + st * 16 + half * 8];
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
+      u32x2 h0, m0, l0, h1, m1, l1;
+      gsplit3(a0, h0, m0, l0);
+      gsplit3(a1, h1, m1, l1);
+      bf16x8 ax[3];
+      ax[0] = __builtin_bit_cast(bf16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
+      ax[1] = __builtin_bit_cast(bf16x8, u32x4{m0.x, m0.y, m1.x, m1.y});
+      ax[2] = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
+      constexpr int PA6[6] = {2, 0, 1, 1, 0, 0};
+      constexpr int PB6[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {          // one output block at a time: 12 fragment registers live, not 12 x TN
+        bf16x8 bx[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          bx[pl] = *reinterpret_cast<const bf16x8*>(Bsb + pl * (C * 32) + ((wn * TN + tn) * 32 + col) * 32 + half * 16);
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[PA6[c]], bx[PB6[c]], acc[tn], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  } else {
 #pragma unroll 1
   for (int kc = 0; kc < NC; ++kc) {
     store_b();
@@ -298,6 +375,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
     if (kc + 1 < NC) load_b(gw, C, (kc + 1) * 32);
     mfma_step(Tt, TP, kc * 32);
     __syncthreads();
+  }
   }
   acc_to_tile();
   __syncthreads();
@@ -338,7 +416,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
   GDN_STAMP(4);
 }
 
-template <int NC, int WM, int WN, int MODE, int PRO>
+template <int NC, int WM, int WN, int MODE, int PRO, bool X3 = false>
 int launch_inst(const GdnArgs& a, hipStream_t stream) {
   constexpr int C = NC * 32, BM = WM * 32, NT = WM * WN * 64;
   const size_t lds = (size_t)(BM * (C + 4) + C * LDK) * sizeof(float);
@@ -348,13 +426,13 @@ int launch_inst(const GdnArgs& a, hipStream_t stream) {
   (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_tile_kernel<NC, WM, WN, MODE, PRO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_tile_kernel<NC, WM, WN, MODE, PRO, X3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_devs.fetch_or(bit, std::memory_order_release);
   }
   const long long grid = (a.M + BM - 1) / BM;
   if (grid <= 0 || grid > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((gdn_tile_kernel<NC, WM, WN, MODE, PRO>), dim3((unsigned)grid), dim3(NT), lds, stream, a);
+  hipLaunchKernelGGL((gdn_tile_kernel<NC, WM, WN, MODE, PRO, X3>), dim3((unsigned)grid), dim3(NT), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -362,7 +440,15 @@ template <int NC, int WM, int WN>
 int launch_mode(const GdnArgs& a, hipStream_t s) {
   if (a.pro == GDN_PRO_CONV3) {
     if (a.mode != GDN_IGDN_BWD) return (int)hipErrorInvalidValue;
+    if (a.x3 && a.wx3) return launch_inst<NC, WM, WN, GDN_IGDN_BWD, GDN_PRO_CONV3, true>(a, s);
     return launch_inst<NC, WM, WN, GDN_IGDN_BWD, GDN_PRO_CONV3>(a, s);
+  }
+  if (a.x3 && a.wx3) {
+    switch (a.mode) {
+      case GDN_IGDN_FWD: return launch_inst<NC, WM, WN, GDN_IGDN_FWD, GDN_PRO_LOAD, true>(a, s);
+      case GDN_GDN_FWD: return launch_inst<NC, WM, WN, GDN_GDN_FWD, GDN_PRO_LOAD, true>(a, s);
+      case GDN_IGDN_BWD: return launch_inst<NC, WM, WN, GDN_IGDN_BWD, GDN_PRO_LOAD, true>(a, s);
+    }
   }
   switch (a.mode) {
     case GDN_IGDN_FWD: return launch_inst<NC, WM, WN, GDN_IGDN_FWD, GDN_PRO_LOAD>(a, s);
@@ -393,7 +479,8 @@ int gdn_tile_rows(int C, long long M, int pro) {
 void gdn_kernel_name(const GdnArgs& a, char* out, int len) {
   int wm, wn;
   pick_shape(a.C, a.M, a.pro == GDN_PRO_CONV3, wm, wn);
-  snprintf(out, len, "gdn_tile_kernel<%d,%d,%d,%d,%d>", a.C / 32, wm, wn, a.mode, a.pro);
+  if (a.x3 && a.wx3) snprintf(out, len, "gdn_tile_kernel<%d,%d,%d,%d,%d,x3>", a.C / 32, wm, wn, a.mode, a.pro);
+  else snprintf(out, len, "gdn_tile_kernel<%d,%d,%d,%d,%d>", a.C / 32, wm, wn, a.mode, a.pro);
 }
 
 int launch_gdn_tile(const GdnArgs& a, hipStream_t s) {

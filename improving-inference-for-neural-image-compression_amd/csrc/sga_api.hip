@@ -328,6 +328,7 @@ struct Deferred {
 // possible when the launch is an unsplit 256-row-tile one with all C = 192 channels in a tile.
 struct PostGdn {
   const float* gamma_w = nullptr; const float* beta = nullptr; float* s_out = nullptr; float* v_out = nullptr;
+  const unsigned short* gamma_w3 = nullptr;      // the same gamma pre-split into bf16 planes (bf16x3 post-phase)
   bool drop_u = false;       // in: the fused launch need not write u (the backward pass uses v / s)
   const float* w3 = nullptr; float* p3 = nullptr;      // in (optional): also form the next (C -> 3) layer's products P = v . w3
   bool p3_done = false;      // out: the fused launch wrote P
@@ -432,7 +433,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     post->fused = h->fused_post && post_tile && a.ksplit <= 1 && (a.Cout == 192 || a.Cout == 256) && a.Npad == a.Cout &&
                   a.epi == EPI_BIAS && a.out_coff == 0 && a.out_cs == a.Cout && post->s_out && post->v_out;
     if (post->fused) {
-      a.post = 1; a.post_w = post->gamma_w; a.post_beta = post->beta; a.post_s = post->s_out; a.post_v = post->v_out;
+      a.post = 1; a.post_w = post->gamma_w; a.post_wx3 = post->gamma_w3; a.post_beta = post->beta; a.post_s = post->s_out; a.post_v = post->v_out;
       if (post->drop_u) a.out = nullptr;
       if (post->w3 && post->p3 && a.Cout == 192 && a.bm == 256) {
         a.post_w3 = post->w3; a.post_p = post->p3;
@@ -868,7 +869,7 @@ int gdn_fwd(sga_handle* h, const PackedConv& pc, const float* beta, float* u, in
     g.C = pc.N; g.mode = inverse ? GDN_IGDN_FWD : GDN_GDN_FWD; g.pro = GDN_PRO_LOAD;
     g.M = (long long)B * Hh * Ww;
     gdn_source(g, u, d);
-    g.w = pc.w; g.beta = beta; g.out = out; g.s_out_p = s_out;
+    g.w = pc.w; g.wx3 = pc.w3; g.x3 = (h->x3 && h->x3_variants) ? 1 : 0; g.beta = beta; g.out = out; g.s_out_p = s_out;
     g.u_out = (d && d->active && write_u) ? u : nullptr;
     g.flops = 2.0 * B * Hh * Ww * (double)pc.Kc * pc.N;
     return gdn_launch(h, g, st);
@@ -898,7 +899,7 @@ int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float*
     g.M = (long long)B * Hh * Ww;
     gdn_source(g, g_v, d);
     if (gpad) { g.pad = gpad; g.wc = pc3->w; g.Hg = Hh; g.Wg = Ww; g.Hp = Hp; g.Wp = Wp; }
-    g.w = pc.w; g.u = u; g.s = s; g.out = g_u; g.v = v;
+    g.w = pc.w; g.wx3 = pc.w3; g.x3 = (h->x3 && h->x3_variants) ? 1 : 0; g.u = u; g.s = s; g.out = g_u; g.v = v;
     g.flops = 2.0 * B * Hh * Ww * (double)pc.Kc * pc.N + (gpad ? 2.0 * B * Hh * Ww * 75.0 * pc.N : 0.0);
     return gdn_launch(h, g, st);
   }
@@ -1103,7 +1104,7 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   for (int L = 0; L < 3; ++L) {
     Deferred d;
     PostGdn pg;
-    pg.gamma_w = h->gs_gdn_f[L].w; pg.beta = h->gs_beta[L]; pg.s_out = h->s[L].p; pg.v_out = h->v[L].p;
+    pg.gamma_w = h->gs_gdn_f[L].w; pg.gamma_w3 = h->gs_gdn_f[L].w3; pg.beta = h->gs_beta[L]; pg.s_out = h->s[L].p; pg.v_out = h->v[L].p;
     pg.drop_u = drop_u;
     if (L == 2 && h->post_p && !h->gs3_generic && (size_t)B * (2 * hh) * (2 * ww) * 80 <= h->p3.cap) {
       pg.w3 = h->gs3_w80; pg.p3 = h->p3.p;

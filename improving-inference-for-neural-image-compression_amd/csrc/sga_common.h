@@ -96,6 +96,7 @@ struct ConvArgs {
   // then sums the slabs and applies the epilogue (deterministic, no atomics).
   // fused IGDN post-phase (256-row unsplit C = 192 launches): out = u, post_s = sqrt(n), post_v = u * sqrt(n)
   int post; const float* post_w; const float* post_beta; float* post_s; float* post_v;
+  const unsigned short* post_wx3;      // gamma pre-split into three bf16 planes (X3 instances), layout as `w3`
   // ... and, with the IGDN, the products of the layer after it (C -> 3): post_p [pixel][80] = post_v . post_w3 (or null)
   const float* post_w3; float* post_p;
   const float* zeros;      // >= 256 bytes of zeros: what taps outside the image load (LDS-DMA instance)
@@ -148,6 +149,7 @@ struct GdnArgs {
   // weights wc [3][C][32] (pack_smallc)
   const float* pad; const float* wc; int Hg, Wg, Hp, Wp;
   const float* w;          // gamma, [C][C]: row = output channel, K contiguous (pack_gdn)
+  const unsigned short* wx3; int x3;   // precision mode bf16x3: gamma pre-split into three bf16 planes (layout of ConvArgs::w3)
   const float* beta;       // forward
   const float* u; const float* s;     // backward: pre-IGDN activation and sqrt(n) of the forward pass
   const float* v;                     // backward, when the forward pass did not store u: v = u*s (then u = v/s; `u` unused)
