@@ -1073,9 +1073,10 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   // or, when the handle names one (fork_name: chosen per geometry by sga_run_steps), right before that launch
   auto tick = [&](const char* name = nullptr) -> int {
     // Never before the FIRST launch: the branch's first kernel would then be a second root node of the captured graph, with
-    // no predecessor inside it.  Measured (round 4, scripts/x3_fork_race.py): bf16x3 mode forked at the root gave 3 different
-    // outcomes in 20 identical 300-iteration graph replays (all diverging at iteration 33), forked after the first launch 20
-    // of 20 identical; eager launches, and the f32 kernels in either position, 20 of 20 (DESIGN_EXPERIMENTS.md A.8).
+    // no predecessor inside it.  Kept as a structural rule (one root per step graph).  It was introduced while hunting the
+    // bf16x3 two-stream nondeterminism and moved the failure rate (3 outcomes in 20 replays -> 0 in 20) without being the
+    // cause: the cause was the packed-f32 VALU hazard beside bf16 MFMA waves (csrc/Makefile, DESIGN_EXPERIMENTS.md A.8b),
+    // which the root fork merely made likelier by co-scheduling the elementwise kernels with the X3 convolutions.
     const bool here = (h->fork_name ? (name && strcmp(name, h->fork_name) == 0) : launches >= fork_at) && launches >= 1;
     if (side && !side_started && here) { side_started = true; SGACHK((*side)()); }
     // second fork point (captured graph only): the branch's BACKWARD half may not start before this launch
