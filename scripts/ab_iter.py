@@ -1,5 +1,6 @@
 """GPU box: A/B of environment switches on the SGA iteration time at the bench shape (cfg 2).
 usage: python scripts/ab_iter.py [--rounds N] "" "SGA_X=1" "SGA_X=1 SGA_Y=0" ...   (each argument = one variant's environment)
+LAB=1 in a variant's environment: the laboratory build (libsga_hip_lab.so) with its extra switches; B, H, W, C: the shape.
 The variants run in separate processes, alternating, N rounds; prints us per iteration (best of 3 x 400 graph replays)."""
 import os
 import subprocess
@@ -12,7 +13,7 @@ sys.path.insert(0, %r)
 import torch, sga_amd
 from sga_amd.codec import SGACodec
 C, B, H, W = int(os.environ.get("C", 192)), int(os.environ.get("B", 8)), int(os.environ.get("H", 256)), int(os.environ.get("W", 256))
-codec = SGACodec(sga_amd.make_synthetic_weights(C, 0), C, B, H, W)
+codec = SGACodec(sga_amd.make_synthetic_weights(C, 0), C, B, H, W, lab=bool(os.environ.get("LAB")))
 x = torch.rand(B, H, W, 3, generator=torch.Generator().manual_seed(1000)).cuda()
 codec.run(x, 0.01, its=100, metrics=False); torch.cuda.synchronize()
 best = 1e9
