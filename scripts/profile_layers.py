@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch, sga_amd
 from sga_amd.codec import SGACodec
 C, B, H, W = int(os.environ.get("C", 192)), int(os.environ.get("B", 8)), int(os.environ.get("H", 256)), int(os.environ.get("W", 256))
-codec = SGACodec(sga_amd.make_synthetic_weights(C, 0), C, B, H, W, precision=os.environ.get("PREC", "f32"))
+codec = SGACodec(sga_amd.make_synthetic_weights(C, 0), C, B, H, W, precision=os.environ.get("PREC", "f32"), lab=bool(os.environ.get("LAB")))
 x = torch.rand(B, H, W, 3, generator=torch.Generator().manual_seed(1000)).cuda()
 codec.run(x, 0.01, its=5, metrics=False)
 its = 40
