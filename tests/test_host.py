@@ -59,6 +59,39 @@ def test_product_library_has_only_the_documented_environment_knobs():
     assert lab_lib.sga_abi_version() == _lib.SGA_ABI_VERSION
 
 
+def test_device_code_has_no_packed_f32_instructions(tmp_path):
+    """Round 4, DESIGN_EXPERIMENTS.md A.8b: on gfx950 a packed-f32 VALU instruction (v_pk_mul_f32 / v_pk_add_f32 /
+    v_pk_fma_f32) returns wrong values in lanes 48..63 while another wave of the SIMD issues bf16 MFMAs
+    (scripts/trans_mfma_repro.hip) -- the cause of the two-stream bf16x3 nondeterminism of rounds 1-3.  The library is built
+    with `-target-feature -packed-fp32-ops` (csrc/Makefile); this test disassembles every gfx950 code object of both builds
+    and fails if a later toolchain or Makefile change lets one back in."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    bundler, objdump = os.path.join(llvm, "clang-offload-bundler"), os.path.join(llvm, "llvm-objdump")
+    if not (os.path.exists(bundler) and os.path.exists(objdump) and shutil.which("objcopy")):
+        pytest.skip("no ROCm LLVM tools here")
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    for lib in (_lib.LIB_PATH, _lib.LAB_LIB_PATH):
+        fat = str(tmp_path / "fat.bin")
+        subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+        data = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(magic), data)]
+        assert len(starts) >= 6, "expected one bundle per HIP translation unit"
+        total = 0
+        for i, b in enumerate(starts):
+            e = starts[i + 1] if i + 1 < len(starts) else len(data)
+            one, co = str(tmp_path / ("b%d.bin" % i)), str(tmp_path / ("b%d.co" % i))
+            open(one, "wb").write(data[b:e])
+            subprocess.run([bundler, "--unbundle", "--type=o", "--input=" + one, "--output=" + co,
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True, capture_output=True)
+            asm = subprocess.run([objdump, "-d", co], check=True, capture_output=True, text=True).stdout
+            total += asm.count("v_mfma_")
+            bad = sorted(set(re.findall(r"v_pk_(?:mul|add|fma)_f32", asm)))
+            assert not bad, "%s: %s in code object %d" % (os.path.basename(lib), bad, i)
+        assert total > 1000      # the disassembly really is the kernels
+
+
 def test_one_hip_runtime_in_the_process():
     """Loading the library (even before anyone imported torch, as build() does) must leave ONE
     libamdhip64 mapped: torch's bundled copy.  Two copies gave SGA_ERR_NO_DEVICE on a GPU box."""
