@@ -104,7 +104,7 @@ SCALE_BOUND_NONE, SCALE_BOUND_BUILT = 0.0, 0.11
 SYMBOLS["sga_op_rate_terms"] = (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P])
 SYMBOLS["sga_set_image_ids"] = (_I, [_P, C.POINTER(C.c_int32), _I])
 SYMBOLS["sga_set_image_seeds"] = (_I, [_P, C.POINTER(C.c_uint64), _I])
-PRECISIONS = {"default": 0, "f32": 1, "bf16x3": 2}
+PRECISIONS = {"default": 0, "f32": 1, "bf16x3": 2, "bf16x2": 3}
 RELAXATIONS = {"sga": 0, "danneal": 1, "unoise": 2, "ste": 3, "none": 4}
 SCHEDULES = {"exp0": 0, "exp": 1}
 SYMBOLS["sga_profile_begin"] = (_I, [_P])

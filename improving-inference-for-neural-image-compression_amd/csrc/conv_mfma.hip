@@ -66,6 +66,14 @@ __device__ __forceinline__ void split3(const f32x4 v, u32x2& h, u32x2& m, u32x2&
   l.y = cvt_pk_bf16(r2 - bf16_lo(m.y), r3 - bf16_hi(m.y));
 }
 
+// 4 floats -> the two upper planes only (precision mode bf16x2: x ~ h + m, |x - h - m| <= 2^-17 |x|)
+__device__ __forceinline__ void split2(const f32x4 v, u32x2& h, u32x2& m) {
+  h.x = cvt_pk_bf16(v.x, v.y);
+  h.y = cvt_pk_bf16(v.z, v.w);
+  m.x = cvt_pk_bf16(v.x - bf16_lo(h.x), v.y - bf16_hi(h.x));
+  m.y = cvt_pk_bf16(v.z - bf16_lo(h.y), v.w - bf16_hi(h.y));
+}
+
 // Instances whose K loop takes its operands by LDS-DMA (global_load_lds_dwordx4): see the GLDS block in conv_tile
 constexpr bool glds_instance(int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3, int POST) {
   // 64-row (2 x 32 KB stages, still 2 workgroups/CU) and 256-row (2 x 56 KB, 1/CU either way).  The 128-row 4-wave
@@ -103,7 +111,9 @@ constexpr int x3_main_floats(int BM, int BN, bool pipelined) {
 }
 constexpr int post_rows(int BM, int BN) { return BM < 128 ? BM : (BN <= 192 ? 128 : 64); }
 constexpr int post_qbufs(int BM) { return BM < 128 ? 1 : 2; }
-template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3, int POST = 0>
+// X3: 0 = f32 MFMA; 1 = bf16x3 (3 planes, 6 products); 2 = bf16x2 (the two upper planes, 3 products: operands rounded to 16
+// mantissa bits; only the pipelined PRO_NONE loop has this form, the post-phase of such an instance stays bf16x3)
+template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, int X3, int POST = 0>
 __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN >= 8)) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -349,10 +359,13 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
   // barrier per stage.  Same operands, same plane order, same k order per accumulator as the single-stage loop: bit-identical.
   if constexpr (X3P) {
     constexpr int ROWB = 32;                                   // bytes per row per plane per stage: 16 bf16
-    constexpr int A_PL = BM * ROWB, B_PL = BN * ROWB, STAGE_B = 3 * (A_PL + B_PL);
+    constexpr int NPL = X3 == 2 ? 2 : 3;                       // operand planes in use (the weights are stored as 3 either way)
+    static_assert(X3 == 1 || X3 == 2, "precision mode");
+    constexpr int A_PL = BM * ROWB, B_PL = BN * ROWB, STAGE_B = NPL * (A_PL + B_PL);
     constexpr int PA2 = BM * 4 / NT;                           // 16-byte f32 pieces (4 k's) of the A stage per thread
     static_assert((BM * 4) % NT == 0 && NT % 4 == 0, "x3 pipelined loader mismatch");
-    constexpr int NBP = BN * 6, PB2 = (NBP + NT - 1) / NT;     // 16-byte pieces of the pre-split weight stage (3 planes x 32 B per row)
+    constexpr int RP = 2 * NPL;                                // 16-byte pieces per weight row and stage (NPL planes x 32 B)
+    constexpr int NBP = BN * RP, PB2 = (NBP + NT - 1) / NT;    // 16-byte pieces of the pre-split weight stage
     char* const sm = reinterpret_cast<char*>(smem);
     const int c4 = tid & 3, prow = tid >> 2;                   // piece (row prow + p * NT / 4, floats c4 * 4 .. + 3 of the stage)
     int q_iy[PA2], q_ix[PA2], q_base[PA2];
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
 #pragma unroll
       for (int k = 0; k < PB2; ++k) {
         const int f = tid + NT * k;
-        const int nl = f / 6, r6 = f - nl * 6;                 // row nl: plane r6 >> 1, 16-byte half r6 & 1
+        const int nl = f / RP, r6 = f - nl * RP;               // row nl: plane r6 >> 1, 16-byte half r6 & 1
         if (NBP % NT == 0 || k + 1 < PB2 || f < NBP)
           qb[k] = *reinterpret_cast<const u32x4*>(wb + (size_t)nl * (a.Cin / BK) * 96 + (r6 >> 1) * 32 + (r6 & 1) * 8);
       }
@@ -399,18 +412,19 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
 #pragma unroll
       for (int p = 0; p < PA2; ++p) {
         u32x2 h, m, l;
-        split3(qa[p], h, m, l);
+        if constexpr (NPL == 3) split3(qa[p], h, m, l);
+        else split2(qa[p], h, m);
         char* dst = st + (prow + p * (NT / 4)) * ROWB + c4 * 8;
         *reinterpret_cast<u32x2*>(dst) = h;
         *reinterpret_cast<u32x2*>(dst + A_PL) = m;
-        *reinterpret_cast<u32x2*>(dst + 2 * A_PL) = l;
+        if constexpr (NPL == 3) *reinterpret_cast<u32x2*>(dst + 2 * A_PL) = l;
       }
 #pragma unroll
       for (int k = 0; k < PB2; ++k) {
         const int f = tid + NT * k;
-        const int nl = f / 6, r6 = f - nl * 6;
+        const int nl = f / RP, r6 = f - nl * RP;
         if (NBP % NT == 0 || k + 1 < PB2 || f < NBP)
-          *reinterpret_cast<u32x4*>(st + 3 * A_PL + (r6 >> 1) * B_PL + nl * ROWB + (r6 & 1) * 16) = qb[k];
+          *reinterpret_cast<u32x4*>(st + NPL * A_PL + (r6 >> 1) * B_PL + nl * ROWB + (r6 & 1) * 16) = qb[k];
       }
     };
     const int nchunk2 = a.Cin / 16;
@@ -432,13 +446,13 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
     }
     __syncthreads();
     const int fa = arow * ROWB + (lane >> 5) * 16;
-    const int fb = 3 * A_PL + brow * ROWB + (lane >> 5) * 16;
+    const int fb = NPL * A_PL + brow * ROWB + (lane >> 5) * 16;
     for (int s2 = s_begin; s2 < s_end; ++s2) {
       const int cur = (s2 - s_begin) & 1;
       const char* const st = sm + cur * STAGE_B;
-      bf16x8 af3[3][TM], bf3[3][TN];
+      bf16x8 af3[NPL][TM], bf3[NPL][TN];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
           af3[pl][tm] = *reinterpret_cast<const bf16x8*>(st + pl * A_PL + fa + tm * 32 * ROWB);
@@ -454,10 +468,12 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
           gload2(ci_l);                                        // stage s2 + 2
         }
       }
-      constexpr int PA6[6] = {2, 0, 1, 1, 0, 0};               // A plane: l, h, m, m, h, h   (smallest products first)
-      constexpr int PB6[6] = {0, 2, 1, 0, 1, 0};               // B plane: h, l, m, h, m, h
+      // bf16x3: A plane l, h, m, m, h, h x B plane h, l, m, h, m, h (smallest products first); bf16x2: m.h, h.m, h.h
+      constexpr int NPR = NPL == 3 ? 6 : 3;
+      constexpr int PA6[6] = {NPL == 3 ? 2 : 1, 0, NPL == 3 ? 1 : 0, 1, 0, 0};
+      constexpr int PB6[6] = {0, NPL == 3 ? 2 : 1, NPL == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
-      for (int c = 0; c < 6; ++c)
+      for (int c = 0; c < NPR; ++c)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -1111,7 +1127,7 @@ __global__ void splitk_reduce_kernel(const ReduceArgs r) {
   }
 }
 
-template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, bool X3 = false, int POST = 0>
+template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, int X3 = 0, int POST = 0>
 int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -1144,14 +1160,21 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+// bf16-pipe PRO_NONE instance: a.x3 == 2 -> the two-plane loop (bf16x2), else three planes (bf16x3)
+template <int TM, int TN, int WM, int WN, int POST = 0>
+int launch_xp(const ConvArgs& a, hipStream_t s) {
+  if (a.x3 == 2) return launch_inst<TM, TN, WM, WN, PRO_NONE, false, 2, POST>(a, s);
+  return launch_inst<TM, TN, WM, WN, PRO_NONE, false, 1, POST>(a, s);
+}
+
 template <int TM, int TN, int WM, int WN>
 int launch_pro(const ConvArgs& a, hipStream_t s) {
   if (a.smallc) return launch_inst<TM, TN, WM, WN, PRO_NONE, true>(a, s);
   if (a.x3) {
     switch (a.pro) {
-      case PRO_NONE: return launch_inst<TM, TN, WM, WN, PRO_NONE, false, true>(a, s);
-      case PRO_SQUARE: return launch_inst<TM, TN, WM, WN, PRO_SQUARE, false, true>(a, s);
-      case PRO_IGDN_BWD: return launch_inst<TM, TN, WM, WN, PRO_IGDN_BWD, false, true>(a, s);
+      case PRO_NONE: return launch_xp<TM, TN, WM, WN>(a, s);
+      case PRO_SQUARE: return launch_inst<TM, TN, WM, WN, PRO_SQUARE, false, 1>(a, s);
+      case PRO_IGDN_BWD: return launch_inst<TM, TN, WM, WN, PRO_IGDN_BWD, false, 1>(a, s);
     }
   }
   switch (a.pro) {
@@ -1190,7 +1213,8 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
   if (a.bm == 256 && a.x3 && a.x3w4 && !a.post) { wm = 2; tm = 4; }
   if (a.bm == 64) tm = 1;
   snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%s,%d>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
-           a.smallc ? "true" : "false", (a.x3 && !a.smallc && bn != 32) ? "true" : "false",
+           a.smallc ? "true" : "false",
+           (a.x3 && !a.smallc && bn != 32) ? ((a.x3 == 2 && a.pro == PRO_NONE) ? "x2" : "true") : "false",
            a.post ? (a.post_p ? 2 : 1) : (a.lowfoot && a.bm == 64 && bn == 192 ? 3 : 0));
 }
 
@@ -1219,10 +1243,10 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
         if (a.post) {
           if (a.ksplit > 1 || a.epi != EPI_BIAS || a.Cout != 192 || a.out_coff != 0 || a.out_cs != 192 || a.post_p)
             return (int)hipErrorInvalidValue;
-          if (a.x3) return launch_inst<1, 3, 2, 2, PRO_NONE, false, true, 1>(a, stream);
+          if (a.x3) return launch_xp<1, 3, 2, 2, 1>(a, stream);
           return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 1>(a, stream);
         }
-        if (a.x3) return launch_inst<1, 3, 2, 2, PRO_NONE, false, true>(a, stream);
+        if (a.x3) return launch_xp<1, 3, 2, 2>(a, stream);
 #ifdef SGA_EXPERIMENTS
         if (a.lowfoot) return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 3>(a, stream);
 #endif
@@ -1233,7 +1257,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
         if (a.post) {
           if (a.ksplit > 1 || a.epi != EPI_BIAS || a.Cout != 192 || a.out_coff != 0 || a.out_cs != 192)
             return (int)hipErrorInvalidValue;
-          if (a.x3) return a.post_p ? (int)hipErrorInvalidValue : launch_inst<2, 3, 4, 2, PRO_NONE, false, true, 1>(a, stream);
+          if (a.x3) return a.post_p ? (int)hipErrorInvalidValue : launch_xp<2, 3, 4, 2, 1>(a, stream);
 #ifdef SGA_EXPERIMENTS
           if (a.post_p) return launch_inst<2, 3, 4, 2, PRO_NONE, false, false, 2>(a, stream);
 #else
@@ -1242,9 +1266,9 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
           return launch_inst<2, 3, 4, 2, PRO_NONE, false, false, 1>(a, stream);
         }
 #ifdef SGA_EXPERIMENTS      // (one wave per SIMD, 128 x 96 per wave: gs2.bwd 343 us against 302 for the 8-wave instance; A.9)
-        if (a.x3 && a.x3w4) return launch_inst<4, 3, 2, 2, PRO_NONE, false, true>(a, stream);
+        if (a.x3 && a.x3w4) return launch_inst<4, 3, 2, 2, PRO_NONE, false, 1>(a, stream);
 #endif
-        if (a.x3) return launch_inst<2, 3, 4, 2, PRO_NONE, false, true>(a, stream);
+        if (a.x3) return launch_xp<2, 3, 4, 2>(a, stream);
         return launch_inst<2, 3, 4, 2, PRO_NONE, false>(a, stream);
       }
       return launch_pro<2, 3, 2, 2>(a, stream);
@@ -1262,7 +1286,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     case 64: return launch_pro<2, 1, 2, 2>(a, stream);
     case 96:
       if (a.smallc || a.pro != PRO_NONE) return (int)hipErrorInvalidValue;
-      if (a.x3) return launch_inst<2, 3, 2, 1, PRO_NONE, false, true>(a, stream);
+      if (a.x3) return launch_xp<2, 3, 2, 1>(a, stream);
       return launch_inst<2, 3, 2, 1, PRO_NONE, false>(a, stream);
     case 32:
       if (a.smallc || a.pro != PRO_NONE) return (int)hipErrorInvalidValue;

@@ -179,6 +179,7 @@ struct sga_handle {
   bool profiling = false;
   bool no_splitk = false;          // SGA_NO_SPLITK=1
   bool x3 = false;                 // precision mode bf16x3 (sga_config.reserved[0] == 2 or SGA_PRECISION=bf16x3)
+  bool x2 = false;                 // precision mode bf16x2 (implies x3: same instances and weight planes; the convolution K loops use two planes)
   bool profile_by_layer = false;   // SGA_PROFILE_BY_LAYER=1: aggregate by call site instead of symbol
   const char* cur_tag = "";
   std::vector<ProfRec> prof;
@@ -448,11 +449,12 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   // 177 us, 96 vs 88 us), so those launches stay on the f32 MFMA kernel (2.21 -> 2.30 img/s).
   a.x3 = (h->x3 && a.w3 && !a.smallc && a.epi != EPI_SHUFFLE3 && a.pro != PRO_IGDN_BWD &&
           a.Npad / a.ntiles_n != 96) ? 1 : 0;
+  if (a.x3 && h->x2 && a.pro == PRO_NONE) a.x3 = 2;      // bf16x2: the two-plane K loop (PRO_NONE instances only)
   { // laboratory (A.8): bf16x3 arithmetic in only one of the two branches, to isolate the two-stream nondeterminism
     static const int only = LAB_ENV("SGA_X3_ONLY") ? atoi(LAB_ENV("SGA_X3_ONLY")) : 0;      // 1: main chain only, 2: hyper branch only
     if ((only == 1 && h->in_hyper) || (only == 2 && !h->in_hyper)) a.x3 = 0; }
   { static const bool w4 = LAB_ENV("SGA_X3_W4") != nullptr && LAB_ENV("SGA_X3_W4")[0] == '1';
-    a.x3w4 = (w4 && a.x3 && a.bm == 256 && !a.post) ? 1 : 0; }
+    a.x3w4 = (w4 && a.x3 == 1 && a.bm == 256 && !a.post) ? 1 : 0; }
   const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
   if (a.ksplit > 1) { a.part = h->cur_part->p; a.slab = n_out; }
   bool gprof_here = false;
@@ -1412,7 +1414,9 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->haN = cfg->bits_back ? 2 * C : C;
   {
     const char* pe = getenv("SGA_PRECISION");
-    h->x3 = cfg->precision == SGA_PRECISION_BF16X3 ||
+    h->x2 = cfg->precision == SGA_PRECISION_BF16X2 ||
+            (cfg->precision == SGA_PRECISION_DEFAULT && pe && strcmp(pe, "bf16x2") == 0);
+    h->x3 = h->x2 || cfg->precision == SGA_PRECISION_BF16X3 ||
             (cfg->precision == SGA_PRECISION_DEFAULT && pe && strcmp(pe, "bf16x3") == 0);
     pe = getenv("SGA_X3_VARIANTS");      // read here: the weight packing below depends on it (bn96_as_192)
     h->x3_variants = !(pe && pe[0] == '0');
@@ -1651,7 +1655,9 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
       return fail(SGA_ERR_HIP);
   }
   env = getenv("SGA_PRECISION");
-  h->x3 = cfg->precision == SGA_PRECISION_BF16X3 ||
+  h->x2 = cfg->precision == SGA_PRECISION_BF16X2 ||
+          (cfg->precision == SGA_PRECISION_DEFAULT && env && strcmp(env, "bf16x2") == 0);
+  h->x3 = h->x2 || cfg->precision == SGA_PRECISION_BF16X3 ||
           (cfg->precision == SGA_PRECISION_DEFAULT && env && strcmp(env, "bf16x3") == 0);
   env = LAB_ENV("SGA_DEBUG_DUMP");
   if (env && env[0]) {

@@ -346,7 +346,7 @@ def parse_args(argv):
                    help="lower bound on the conditional's sigma; default: what the mirrored script executes -- none (0) "
                         "for sga.py and its siblings, which never build the tfc GaussianConditional layer "
                         "(sga.py:130-133), 0.11 for mbt2018.py, which calls it (mbt2018.py:77-80)")
-    c.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+    c.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x2"],
                    help="arithmetic of the conv contractions (DESIGN.md 3.1b); f32 = fp32 MFMA")
     c.add_argument("--check_finite", action="store_true",
                    help="test the logged objective (every 100 iterations and the last) of every launch and abort with the "

@@ -64,6 +64,15 @@ def test_full_run_bf16x3_mode_within_north_star_tolerance(gpu_out_dir, golden):
     assert rep["resolves_1e3_bpp"], rep
 
 
+@pytest.mark.parametrize("golden", ["full_run_oracle.json", "full_run_oracle_fitted.json"])
+def test_full_run_bf16x2_mode_within_north_star_tolerance(gpu_out_dir, golden):
+    """The fast precision mode (two bf16 planes per convolution operand: 16 mantissa bits, include/sga_hip.h) is not
+    f32-grade per step, but what the north star asks for is the END of a 2000-step run -- 1e-3 bpp / 0.01 dB against the
+    reference -- and SGA is a stochastic optimiser whose own seed spread is 10x the tolerance: same sets, same criterion."""
+    rep = _acceptance(gpu_out_dir, golden, "bf16x2", "_bf16x2")
+    assert rep["resolves_1e3_bpp"], rep
+
+
 def _inputs(cfg):
     if cfg.get("inputs") == "lowpass":
         return sga_amd.make_lowpass_images(cfg["B"], cfg["H"], cfg["W"], seed=cfg["x_seed"])

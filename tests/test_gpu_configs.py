@@ -70,6 +70,103 @@ def test_step_at_config_shape(C, H, W, f64, sb, precision, gpu_out_dir):
     codec.close()
 
 
+# (B, H, W) chosen so that the launch planner of csrc/sga_api.hip (conv_launch / pick_ksplit: tile height 64 / 128 / 256 rows by
+# the number of 128-row tiles, split-K by grid efficiency, IGDN post-phase only in unsplit launches, XCD-aware tile order only
+# when the tile count is a multiple of 8, phase pairing only when the whole 4-phase grid is resident) takes a different branch
+# for at least one layer at each entry; the comment names the 128-row tile count of the largest layer (gs2.fwd, per phase x 4).
+PLAN_GEOMS = [
+    (192, 1, 128, 128),     # 32 x 4 tiles: 64-row tiles everywhere, deep split-K
+    (192, 8, 128, 128),     # 256 x 4: the 64-row / 128-row boundary (bm64_max)
+    (192, 3, 128, 192),     # 144: odd image count, tile count not a multiple of 8
+    (192, 2, 256, 256),     # 256
+    (192, 4, 256, 256),     # 512: 256-row tiles become eligible
+    (192, 5, 192, 320),     # 469 (ragged last tile)
+    (192, 6, 256, 192),     # 576: 1.1 rounds of 128-row tiles -> the planner's 64-row choice
+    (192, 7, 224, 224),     # 686, 14 x 14 latents
+    (192, 3, 384, 384),     # 864
+    (192, 1, 512, 512),     # 512, one image: XCD remap with one image per 8 XCDs
+    (192, 2, 400, 304),     # H, W not multiples of 16 or 64: crops in every transposed layer
+    (192, 1, 640, 384),     # 480
+    (256, 2, 256, 256),     # C = 256 (BN = 256 tiles, LDS-DMA loop at 256 rows)
+    (256, 1, 448, 320),
+    (128, 4, 256, 256),     # C = 128: 128-wide tiles
+]
+
+
+def relu_kink_margin(orc64, z_tilde):
+    """Per image: the smallest |pre-activation| of the two ReLU layers of h_s (nn_models.py:152-158), relative to the layer's
+    rms.  A unit within float32 summation noise of its kink (~1e-5 of the rms at K = 1200 ... 4800) is switched on or off by the
+    summation ORDER -- split-K count, tile width -- in any float32 implementation, and its whole contribution (0.1-0.5 % of the
+    ~100 gz elements in its receptive field) appears or disappears.  Found by this sweep at (192, 4, 256, 256): unit (channel
+    249, 13, 12) of image 0 sits at 3e-6 of the rms; the f32 path deviates 4.8e-4 there with split-K targets 128 / 384 / 768 and
+    1e-5 with 256 / 512 or 96-wide tiles (scripts/gz_probe2.py), the float64 oracle with that unit's mask flipped agrees."""
+    import torch.nn.functional as F
+    from oracle.sga_oracle import _nchw
+    t = _nchw(torch.as_tensor(z_tilde, dtype=torch.float64))
+    p0 = orc64._conv_up(t, "hs.k0", "hs.b0")
+    p1 = orc64._conv_up(F.relu(p0), "hs.k1", "hs.b1")
+    m = []
+    for p in (p0, p1):
+        a = p.abs()
+        m.append((a.flatten(1).min(dim=1).values / a.pow(2).mean().sqrt()).numpy())
+    return np.minimum(m[0], m[1])
+
+
+@pytest.mark.parametrize("C,B,H,W", PLAN_GEOMS)
+def test_step_across_launch_plans(C, B, H, W, gpu_out_dir, monkeypatch):
+    """One SGA evaluation (sga.py:86-164) at geometries that steer the launch planner through its branches, both precision
+    modes, vs the float64 oracle: the plan may only change speed and summation order, never the result beyond float32
+    rounding.  Also: the graph replay of 12 iterations equals the eager launches of the same plan bit for bit."""
+    from sga_amd.codec import SGACodec
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    x = np.random.RandomState(100 + B).rand(B, H, W, 3).astype(np.float32)
+    orc64 = SGAOracle(w, dtype=torch.float64)
+    yo, zo = SGAOracle(w).encode(x)
+    seed, it, T, lmbda = 5, 7, 0.25, 0.02
+    u_y = philox.sga_uniforms(yo.numel(), it, 0, seed)
+    u_z = philox.sga_uniforms(zo.numel(), it, 1, seed)
+    want = orc64.step(x, yo, zo, T, u_y, u_z, lmbda)
+    kink = relu_kink_margin(orc64, want["z_tilde"])
+    # what ANOTHER float32 implementation (the oracle in float32: oneDNN summation order) deviates from float64 at this input:
+    # with the raw sigma of sga.py:130-133 an element at |y - mu| ~ 0.5 has d(-log p)/dy ~ 1 / sigma, and the float32 rounding of
+    # mu moves it by 1e-6 / sigma -- 2.6e-4 of max |gy| at (192, 3, 384, 384) in the float32 oracle itself
+    w32 = SGAOracle(w).step(x, yo, zo, T, u_y, u_z, lmbda)
+    gy64, gz64 = want["gy"].numpy(), want["gz"].numpy()
+    f32_gy = rel_err(w32["gy"].numpy(), gy64)
+    f32_gz = np.abs(w32["gz"].numpy().astype(np.float64) - gz64).reshape(B, -1).max(axis=1) / np.abs(gz64).max()
+    for precision in ("f32", "bf16x3"):
+        codec = SGACodec(w, C, B, H, W, precision=precision)
+        y, z = codec.encode(x)
+        assert rel_err(y.cpu().numpy(), yo.numpy()) < 2e-5 and rel_err(z.cpu().numpy(), zo.numpy()) < 2e-5
+        got = codec.step_grads(x, yo.numpy(), zo.numpy(), T, lmbda, seed=seed, it=it)
+        gz = got["gz"].cpu().numpy().astype(np.float64)
+        dz = np.abs(gz - gz64).reshape(B, -1) / np.abs(gz64).max()
+        ez = dz.max(axis=1)                                                          # per image
+        errs = dict(gy=rel_err(got["gy"].cpu().numpy(), gy64), gz=float(ez.max()),
+                    rd_loss=abs(float(got["rd_loss"]) / float(want["rd_loss"]) - 1))
+        report(gpu_out_dir, test="plan_step", C=C, B=B, H=H, W=W, precision=precision, kink_margin=kink.tolist(),
+               gz_per_image=ez.tolist(), f32_oracle_gy=f32_gy, f32_oracle_gz_per_image=f32_gz.tolist(), **errs)
+        assert errs["rd_loss"] < 1e-5, (precision, errs)
+        # as close to float64 as another float32 implementation is (3 x), or 1e-4 where that is smaller
+        assert errs["gy"] < max(1e-4, 3 * f32_gy), (precision, errs, f32_gy)
+        for b in range(B):
+            if ez[b] < max(1e-4, 3 * f32_gz[b]):
+                continue
+            # ... or an h_s ReLU unit of this image within float32 noise of its kink was switched the other way by the
+            # summation order: bounded (one unit carries < 0.5 % of a gradient) and local (its receptive field in z)
+            assert kink[b] < 3e-5 and ez[b] < 5e-3 and (dz[b] > 1e-4).mean() < 0.03, (precision, b, ez.tolist(), kink.tolist())
+        a = codec.run(x, lmbda, its=12, t0=4, annealing_rate=0.05, seed=3)
+        b = codec.run(x, lmbda, its=12, t0=4, annealing_rate=0.05, seed=3)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), precision
+        codec.close()
+        monkeypatch.setenv("SGA_NO_GRAPH", "1")
+        eager = SGACodec(w, C, B, H, W, precision=precision)
+        monkeypatch.delenv("SGA_NO_GRAPH")
+        c = eager.run(x, lmbda, its=12, t0=4, annealing_rate=0.05, seed=3)
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]), (precision, "graph replay != eager launches")
+        eager.close()
+
+
 @pytest.mark.parametrize("H,W", [(512, 768)])
 def test_bits_back_step_at_kodak_size(H, W, gpu_out_dir):
     """cfg 5: one bits-back evaluation (bb_sga.py:93-158) at Kodak size vs the float64 oracle."""

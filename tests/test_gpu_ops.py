@@ -93,6 +93,35 @@ def test_layer_forward(layer, C, precision, gpu_out_dir):
     assert e < 2e-5, f"{layer} C={C}: {where_bad(got, want, 2e-5)}"
 
 
+@pytest.mark.parametrize("C", [64, 192, 256])
+@pytest.mark.parametrize("layer", list(LAYER_IN))
+def test_layer_forward_and_backward_bf16x2(layer, C, gpu_out_dir):
+    """The fast precision mode (SGA_PRECISION_BF16X2, include/sga_hip.h: convolution operands rounded to 16 mantissa bits --
+    two bf16 planes, three plane products, f32 accumulation).  NOT f32-grade by construction (2^-17 per operand), so its own
+    bound: 5e-5 of the output scale after a layer incl. its GDN / IGDN, forward and backward (measured: 1.1e-5 / 5.4e-6 at
+    worst over the 42 cases; the f32-grade bounds above are 2e-5 / 5e-5).  Same asymmetric kernels, odd sizes and float64 references as the tests above; also checks that the mode is
+    not silently the three-plane one (the results differ) nor the f32 one."""
+    codec, orc, orc64, _ = get_codec(C, "bf16x2")
+    x = _layer_input(layer, C)
+    want = orc.layer_fwd(layer, x).numpy()
+    got = codec.layer_fwd(layer, x).cpu().numpy()
+    e = rel_err(got, want)
+    eb = None
+    if layer in ("GS0", "GS1", "GS2", "GS3", "HS0", "HS1", "HS2"):
+        xb = _layer_input(layer, C, seed=3)
+        xt = torch.tensor(xb, dtype=torch.float64, requires_grad=True)
+        out = orc64.layer_fwd(layer, xt)
+        g_out = np.random.RandomState(5).standard_normal(tuple(out.shape)).astype(np.float32)
+        (wantb,) = torch.autograd.grad(out, xt, torch.tensor(g_out, dtype=torch.float64))
+        eb = rel_err(codec.layer_bwd(layer, xb, g_out).cpu().numpy(), wantb.numpy())
+    report(gpu_out_dir, "layer_bf16x2", layer=layer, C=C, rel_err_fwd=e, rel_err_bwd=eb)
+    assert e < 5e-5, f"{layer} C={C}: {where_bad(got, want, 5e-5)}"
+    assert eb is None or eb < 5e-5, (layer, C, eb)
+    if layer in ("GS1", "GS2", "HS1", "HA1") and C >= 128:      # C-channel inputs on the bf16 pipe: the planes really are two
+        x3 = get_codec(C, "bf16x3")[0].layer_fwd(layer, x).cpu().numpy()
+        assert rel_err(got, x3) > 1e-7, "bf16x2 produced the bf16x3 result bit for bit: the two-plane loop did not run"
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("C", [64, 192, 256])
 @pytest.mark.parametrize("layer", ["GS0", "GS1", "GS2", "GS3", "HS0", "HS1", "HS2"])

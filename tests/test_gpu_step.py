@@ -90,6 +90,32 @@ def test_step_grads_injected_noise(C, B, H, W, T, precision, gpu_out_dir):
     assert np.allclose(got["psnr"].cpu().numpy(), ref["psnr"].numpy(), atol=2e-3)
 
 
+@pytest.mark.parametrize("C,B,H,W", SHAPES + [(192, 2, 128, 128)])
+def test_step_grads_bf16x2(C, B, H, W, gpu_out_dir):
+    """The complete step in the fast precision mode vs float64 autograd of the oracle.  Convolution operands carry 16
+    mantissa bits there, so the bound is that of the mode, not of float32: gradients to 3e-4 of their maximum (measured 3e-6 ...
+    3e-5 at these shapes; the f32-grade bound is 1e-4), the logged scalars to 1e-5 as in the other modes.  Reproducible bit for bit like the other modes."""
+    codec, orc, orc64 = setup(C, B, H, W, "bf16x2")
+    x = image(B, H, W, seed=1)
+    yo, zo = orc.encode(x)
+    rng = np.random.RandomState(9)
+    y0 = (yo.numpy() + 0.3 * rng.standard_normal(tuple(yo.shape))).astype(np.float32)
+    z0 = (zo.numpy() + 0.3 * rng.standard_normal(tuple(zo.shape))).astype(np.float32)
+    u_y = rng.uniform(1e-4, 1 - 1e-4, (y0.size, 2)).astype(np.float32)
+    u_z = rng.uniform(1e-4, 1 - 1e-4, (z0.size, 2)).astype(np.float32)
+    ref = orc64.step(x, y0, z0, 0.3, u_y, u_z, 0.01)
+    got = codec.step_grads(x, y0, z0, 0.3, 0.01, u_y=u_y, u_z=u_z)
+    again = codec.step_grads(x, y0, z0, 0.3, 0.01, u_y=u_y, u_z=u_z)
+    ey = rel_err(got["gy"].cpu().numpy(), ref["gy"].numpy())
+    ez = rel_err(got["gz"].cpu().numpy(), ref["gz"].numpy())
+    report(gpu_out_dir, "step_grads_bf16x2", C=C, B=B, H=H, W=W, rel_err_gy=ey, rel_err_gz=ez,
+           rd_loss=got["rd_loss"], rd_loss_ref=ref["rd_loss"])
+    assert ey < 3e-4 and ez < 3e-4, (ey, ez)
+    for k in ("rd_loss", "train_mse", "train_bpp"):
+        assert abs(got[k] - ref[k]) <= 2e-5 * abs(ref[k]), (k, got[k], ref[k])
+    assert torch.equal(got["gy"], again["gy"]) and torch.equal(got["gz"], again["gz"])
+
+
 def low_sigma_weights(C):
     """Synthetic weights whose predicted scales straddle 0.11 (h_s output bias of the log-scale half
     lowered by 2.5: sigma ~ 0.03 ... 0.5), so that sga_config.scale_bound changes the objective."""
