@@ -112,7 +112,7 @@ constexpr int x3_main_floats(int BM, int BN, bool pipelined) {
 constexpr int post_rows(int BM, int BN) { return BM < 128 ? BM : (BN <= 192 ? 128 : 64); }
 constexpr int post_qbufs(int BM) { return BM < 128 ? 1 : 2; }
 // X3: 0 = f32 MFMA; 1 = bf16x3 (3 planes, 6 products); 2 = bf16x2 (the two upper planes, 3 products: operands rounded to 16
-// mantissa bits; only the pipelined PRO_NONE loop has this form, the post-phase of such an instance stays bf16x3)
+// mantissa bits; only the pipelined PRO_NONE loop and the post-phase of such an instance have this form)
 template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, int X3, int POST = 0>
 __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN >= 8)) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = WM * WN * 64;
@@ -414,7 +414,10 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
         u32x2 h, m, l;
         if constexpr (NPL == 3) split3(qa[p], h, m, l);
         else split2(qa[p], h, m);
-        char* dst = st + (prow + p * (NT / 4)) * ROWB + c4 * 8;
+        // the two 16-byte halves of a row are swapped in rows 8..15 (mod 16): a ds_read_b128 is served 16 lanes at a time, and
+        // 16 rows x 16 bytes at a 32-byte pitch would hit every bank twice (45 % bank conflicts measured, r04_pmc_kernels.txt)
+        const int row = prow + p * (NT / 4);
+        char* dst = st + row * ROWB + (((c4 >> 1) ^ ((row >> 3) & 1)) * 16) + (c4 & 1) * 8;
         *reinterpret_cast<u32x2*>(dst) = h;
         *reinterpret_cast<u32x2*>(dst + A_PL) = m;
         if constexpr (NPL == 3) *reinterpret_cast<u32x2*>(dst + 2 * A_PL) = l;
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
         const int f = tid + NT * k;
         const int nl = f / RP, r6 = f - nl * RP;
         if (NBP % NT == 0 || k + 1 < PB2 || f < NBP)
-          *reinterpret_cast<u32x4*>(st + NPL * A_PL + (r6 >> 1) * B_PL + nl * ROWB + (r6 & 1) * 16) = qb[k];
+          *reinterpret_cast<u32x4*>(st + NPL * A_PL + (r6 >> 1) * B_PL + nl * ROWB + (((r6 & 1) ^ ((nl >> 3) & 1)) * 16)) = qb[k];
       }
     };
     const int nchunk2 = a.Cin / 16;
@@ -445,8 +448,9 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
       }
     }
     __syncthreads();
-    const int fa = arow * ROWB + (lane >> 5) * 16;
-    const int fb = NPL * A_PL + brow * ROWB + (lane >> 5) * 16;
+    const int hsw = ((lane >> 5) ^ ((lane >> 3) & 1)) * 16;      // (arow, brow and the + 32 * t rows all have row bits 3 = lane bit 3)
+    const int fa = arow * ROWB + hsw;
+    const int fb = NPL * A_PL + brow * ROWB + hsw;
     for (int s2 = s_begin; s2 < s_end; ++s2) {
       const int cur = (s2 - s_begin) & 1;
       const char* const st = sm + cur * STAGE_B;
@@ -765,8 +769,10 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
     // bf16x3 form of the contraction (X3 instances): n = gamma . u^2 on v_mfma_f32_32x32x16_bf16 in 16-wide stages -- u^2 is
     // split into its three bf16 planes as the fragments leave the tile (8 floats per lane and stage), gamma comes pre-split
     // (a.post_wx3, the planes sga_create packs for every weight) through the gamma buffers as [plane][C][32 bytes]
-    constexpr int QSTG = 3 * C * 32;                 // bytes per staged gamma stage (three planes x C rows x 16 bf16)
-    constexpr int NQX = X3 ? (C * 6 + NT - 1) / NT : 1;
+    // (bf16x2 instances, X3 == 2: the two upper planes of both operands, three products, like the K loop)
+    constexpr int QPL = X3 == 2 ? 2 : 3, QRP = 2 * QPL;        // planes in use; 16-byte pieces per gamma row and stage
+    constexpr int QSTG = QPL * C * 32;               // bytes per staged gamma stage (QPL planes x C rows x 16 bf16)
+    constexpr int NQX = X3 ? (C * QRP + NT - 1) / NT : 1;
     u32x4 qx[NQX];
     char* const Bqb = reinterpret_cast<char*>(Bq);
     auto load_qx = [&](int st) {                     // stage st = k's [16 st, 16 st + 16)
@@ -774,8 +780,8 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
 #pragma unroll
       for (int k = 0; k < NQX; ++k) {
         const int f = tid + NT * k;
-        const int nl = f / 6, r6 = f - nl * 6;
-        if ((C * 6) % NT == 0 || k + 1 < NQX || f < C * 6)
+        const int nl = f / QRP, r6 = f - nl * QRP;
+        if ((C * QRP) % NT == 0 || k + 1 < NQX || f < C * QRP)
           qx[k] = *reinterpret_cast<const u32x4*>(wx + (size_t)nl * (C / 32) * 96 + (r6 >> 1) * 32 + (r6 & 1) * 8);
       }
     };
@@ -783,9 +789,9 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
 #pragma unroll
       for (int k = 0; k < NQX; ++k) {
         const int f = tid + NT * k;
-        const int nl = f / 6, r6 = f - nl * 6;
-        if ((C * 6) % NT == 0 || k + 1 < NQX || f < C * 6)
-          *reinterpret_cast<u32x4*>(Bqb + buf * QSTG + (r6 >> 1) * (C * 32) + nl * 32 + (r6 & 1) * 16) = qx[k];
+        const int nl = f / QRP, r6 = f - nl * QRP;
+        if ((C * QRP) % NT == 0 || k + 1 < NQX || f < C * QRP)
+          *reinterpret_cast<u32x4*>(Bqb + buf * QSTG + (r6 >> 1) * (C * 32) + nl * 32 + (((r6 & 1) ^ ((nl >> 3) & 1)) * 16)) = qx[k];   // halves swapped in rows 8..15 mod 16 (bank conflicts, see the K loop)
       }
     };
     lds_barrier();                                   // main-loop LDS is dead from here on
@@ -826,22 +832,23 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
           f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
           a0 = a0 * a0; a1 = a1 * a1;
           u32x2 h0, m0, l0, h1, m1, l1;
-          split3(a0, h0, m0, l0);
-          split3(a1, h1, m1, l1);
-          bf16x8 ax[3];
+          if constexpr (QPL == 3) { split3(a0, h0, m0, l0); split3(a1, h1, m1, l1); }
+          else { split2(a0, h0, m0); split2(a1, h1, m1); }
+          bf16x8 ax[QPL];
           ax[0] = __builtin_bit_cast(bf16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
           ax[1] = __builtin_bit_cast(bf16x8, u32x4{m0.x, m0.y, m1.x, m1.y});
-          ax[2] = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
-          bf16x8 bx[3][PTN];
+          if constexpr (QPL == 3) ax[2] = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
+          bf16x8 bx[QPL][PTN];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
+          for (int pl = 0; pl < QPL; ++pl)
 #pragma unroll
             for (int tn = 0; tn < PTN; ++tn)
-              bx[pl][tn] = *reinterpret_cast<const bf16x8*>(Bs3 + pl * (C * 32) + ((n2 * PTN + tn) * 32 + col) * 32 + half * 16);
-          constexpr int PA6[6] = {2, 0, 1, 1, 0, 0};   // A plane: l, h, m, m, h, h   (smallest products first)
-          constexpr int PB6[6] = {0, 2, 1, 0, 1, 0};   // B plane: h, l, m, h, m, h
+              bx[pl][tn] = *reinterpret_cast<const bf16x8*>(Bs3 + pl * (C * 32) + ((n2 * PTN + tn) * 32 + col) * 32 + ((half ^ ((col >> 3) & 1)) * 16));
+          constexpr int NQP = QPL == 3 ? 6 : 3;        // three planes: A l, h, m, m, h, h x B h, l, m, h, m, h; two: m.h, h.m, h.h
+          constexpr int PA6[6] = {QPL == 3 ? 2 : 1, 0, QPL == 3 ? 1 : 0, 1, 0, 0};
+          constexpr int PB6[6] = {0, QPL == 3 ? 2 : 1, QPL == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
-          for (int c = 0; c < 6; ++c)
+          for (int c = 0; c < NQP; ++c)
 #pragma unroll
             for (int tn = 0; tn < PTN; ++tn)
               acc2[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[PA6[c]], bx[PB6[c]][tn], acc2[tn], 0, 0, 0);

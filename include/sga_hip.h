@@ -87,8 +87,8 @@ typedef struct sga_config {
  *             parity suite.  Measured: single layers 1.1e-5 (forward) / 5.4e-6 (data-gradient) of the output scale;
  *             one complete step at 8 x 256x256, C = 192: gy 3.5e-4, gz 3.8e-3 of their maxima (f32 path: 1.1e-5 /
  *             2.3e-5 -- gz passes through 1 / sigma); the 2000-step acceptance sets end within the north-star
- *             tolerance (mean dBPP 1.1e-4 +- 1.3e-4 and -1e-5 +- 9e-5).  Convolution K loops only; the C x C
- *             contractions with gamma stay BF16X3. */
+ *             tolerance (mean dBPP 1.1e-4 +- 1.3e-4 and -1e-5 +- 9e-5).  Convolution K loops and the IGDN post-phase of
+ *             those launches; the stand-alone GDN tile kernel and the prologue-transform instances stay BF16X3. */
 typedef enum sga_precision { SGA_PRECISION_DEFAULT = 0, SGA_PRECISION_F32_MFMA = 1, SGA_PRECISION_BF16X3 = 2,
                              SGA_PRECISION_BF16X2 = 3 } sga_precision;
 

@@ -333,7 +333,7 @@ def test_run_trace_with_more_than_eight_images(gpu_out_dir):
 
 
 @pytest.mark.parametrize("graph", [True, False])
-@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("precision", PRECISIONS + ["bf16x2"])
 def test_run_deterministic(precision, graph, gpu_out_dir, monkeypatch):
     """Same seed -> bit-identical rounded latents AND metrics, hipGraph replay or eager two-stream
     launches, both precision modes (no atomics on the gradient path; the f64 sums feeding the
