@@ -107,7 +107,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // X3P block in the kernel); the prologue-transform instances keep the single-stage 32-wide loop
 constexpr bool x3_pipelined(int PRO, bool SMALLC, bool X3) { return X3 && !SMALLC && PRO == PRO_NONE; }
 constexpr int x3_main_floats(int BM, int BN, bool pipelined) {
-  return pipelined ? 2 * 3 * (BM + BN) * 32 / 4 : 3 * (BM + BN) * X3_PITCH / 4;
+  return pipelined ? 2 * 3 * ((BM + BN) * 32 + 128) / 4 : 3 * (BM + BN) * X3_PITCH / 4;      // (+ 128: the weight planes' bank offset)
 }
 constexpr int post_rows(int BM, int BN) { return BM < 128 ? BM : (BN <= 192 ? 128 : 64); }
 constexpr int post_qbufs(int BM) { return BM < 128 ? 1 : 2; }
@@ -361,7 +361,9 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
     constexpr int ROWB = 32;                                   // bytes per row per plane per stage: 16 bf16
     constexpr int NPL = X3 == 2 ? 2 : 3;                       // operand planes in use (the weights are stored as 3 either way)
     static_assert(X3 == 1 || X3 == 2, "precision mode");
-    constexpr int A_PL = BM * ROWB, B_PL = BN * ROWB, STAGE_B = NPL * (A_PL + B_PL);
+    // weight planes 96 / 128 bytes further apart than their size: the loader's 16 lanes of a ds_write_b128 pass hold the same row of
+    // all NPL planes, which would otherwise land on the same banks (plane size = 0 mod 256 bytes: 3- / 2-way conflicts)
+    constexpr int A_PL = BM * ROWB, B_PL = BN * ROWB + (NPL == 3 ? 96 : 128), STAGE_B = NPL * (A_PL + B_PL);
     constexpr int PA2 = BM * 4 / NT;                           // 16-byte f32 pieces (4 k's) of the A stage per thread
     static_assert((BM * 4) % NT == 0 && NT % 4 == 0, "x3 pipelined loader mismatch");
     constexpr int RP = 2 * NPL;                                // 16-byte pieces per weight row and stage (NPL planes x 32 B)
@@ -771,7 +773,9 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
     // (a.post_wx3, the planes sga_create packs for every weight) through the gamma buffers as [plane][C][32 bytes]
     // (bf16x2 instances, X3 == 2: the two upper planes of both operands, three products, like the K loop)
     constexpr int QPL = X3 == 2 ? 2 : 3, QRP = 2 * QPL;        // planes in use; 16-byte pieces per gamma row and stage
-    constexpr int QSTG = QPL * C * 32;               // bytes per staged gamma stage (QPL planes x C rows x 16 bf16)
+    constexpr int QPLB = C * 32 + (QPL == 3 ? 96 : 128);       // plane pitch: + 96 / 128 bytes against write bank conflicts (see the K loop)
+    constexpr int QSTG = QPL * QPLB;                 // bytes per staged gamma stage (QPL planes x C rows x 16 bf16)
+    static_assert(QSTG <= C * LDK * 4, "gamma stage must fit the f32 chunk buffer");
     constexpr int NQX = X3 ? (C * QRP + NT - 1) / NT : 1;
     u32x4 qx[NQX];
     char* const Bqb = reinterpret_cast<char*>(Bq);
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
         const int f = tid + NT * k;
         const int nl = f / QRP, r6 = f - nl * QRP;
         if ((C * QRP) % NT == 0 || k + 1 < NQX || f < C * QRP)
-          *reinterpret_cast<u32x4*>(Bqb + buf * QSTG + (r6 >> 1) * (C * 32) + nl * 32 + (((r6 & 1) ^ ((nl >> 3) & 1)) * 16)) = qx[k];   // halves swapped in rows 8..15 mod 16 (bank conflicts, see the K loop)
+          *reinterpret_cast<u32x4*>(Bqb + buf * QSTG + (r6 >> 1) * QPLB + nl * 32 + (((r6 & 1) ^ ((nl >> 3) & 1)) * 16)) = qx[k];   // halves swapped in rows 8..15 mod 16 (bank conflicts, see the K loop)
       }
     };
     lds_barrier();                                   // main-loop LDS is dead from here on
@@ -843,7 +847,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
           for (int pl = 0; pl < QPL; ++pl)
 #pragma unroll
             for (int tn = 0; tn < PTN; ++tn)
-              bx[pl][tn] = *reinterpret_cast<const bf16x8*>(Bs3 + pl * (C * 32) + ((n2 * PTN + tn) * 32 + col) * 32 + ((half ^ ((col >> 3) & 1)) * 16));
+              bx[pl][tn] = *reinterpret_cast<const bf16x8*>(Bs3 + pl * QPLB + ((n2 * PTN + tn) * 32 + col) * 32 + ((half ^ ((col >> 3) & 1)) * 16));
           constexpr int NQP = QPL == 3 ? 6 : 3;        // three planes: A l, h, m, m, h, h x B h, l, m, h, m, h; two: m.h, h.m, h.h
           constexpr int PA6[6] = {QPL == 3 ? 2 : 1, 0, QPL == 3 ? 1 : 0, 1, 0, 0};
           constexpr int PB6[6] = {0, QPL == 3 ? 2 : 1, QPL == 3 ? 1 : 0, 0, 1, 0};

@@ -209,6 +209,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
   // leave no registers for it)
   // (bf16x3 form of the contraction, X3: gamma comes pre-split into its bf16 planes -- a.wx3, the planes sga_create packs
   //  for every weight -- one 16-wide stage at a time as [plane][C][32 bytes]; see the contraction below)
+  constexpr int GPLB = C * 32 + 96;              // plane pitch of the staged gamma: + 96 bytes against write bank conflicts (conv_mfma.hip)
+  static_assert(3 * GPLB <= C * LDK * 4, "gamma stage must fit Bs");
   constexpr int NBX = X3 ? (C * 6 + NT - 1) / NT : 1;
   u32x4 bxr[NBX];
   char* const Bsb = reinterpret_cast<char*>(Bs);
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
       if ((C * 6) % NT == 0 || k + 1 < NBX || f < C * 6)
         // (the two 16-byte halves swapped in rows 8..15 mod 16: a ds_read_b128 is served 16 lanes at a time, and 16 rows x 16 bytes at
         //  a 32-byte pitch would hit every bank twice -- 41 % bank conflicts measured, profiles/r04_pmc_kernels.txt)
-        *reinterpret_cast<u32x4*>(Bsb + (r6 >> 1) * (C * 32) + nl * 32 + (((r6 & 1) ^ ((nl >> 3) & 1)) * 16)) = bxr[k];
+        *reinterpret_cast<u32x4*>(Bsb + (r6 >> 1) * GPLB + nl * 32 + (((r6 & 1) ^ ((nl >> 3) & 1)) * 16)) = bxr[k];
     }
   };
   if constexpr (MODE != GDN_IGDN_BWD) { if constexpr (X3) load_bx(0); else load_b(gw, C, 0); }
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
         bf16x8 bx[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          bx[pl] = *reinterpret_cast<const bf16x8*>(Bsb + pl * (C * 32) + ((wn * TN + tn) * 32 + col) * 32 + ((half ^ ((col >> 3) & 1)) * 16));
+          bx[pl] = *reinterpret_cast<const bf16x8*>(Bsb + pl * GPLB + ((wn * TN + tn) * 32 + col) * 32 + ((half ^ ((col >> 3) & 1)) * 16));
 #pragma unroll
         for (int c = 0; c < 6; ++c)
           acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[PA6[c]], bx[PB6[c]], acc[tn], 0, 0, 0);
