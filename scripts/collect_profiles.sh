@@ -31,6 +31,13 @@ python scripts/perf_configs.py bf16x3 > $O/configs_bf16x3.txt 2>&1
 python scripts/timeline_from_trace.py $(ls $O/prof_graph_x3/*/*kernel_trace.csv) 100 > $O/timeline_iteration_bf16x3.txt 2>&1
 cp $O/prof_graph_x3/*/*kernel_stats.csv $O/graph_its200_bf16x3_kernel_stats.csv
 B=1 python scripts/profile_layers.py > $O/layers_hipevents_b1.txt 2>&1
+# -- the fast precision mode (bf16x2, bench.py's `fast_precision`): layers, configs, kernel stats of the graph replay
+PREC=bf16x2 python scripts/profile_layers.py > $O/layers_hipevents_bf16x2.txt 2>&1
+python scripts/perf_configs.py bf16x2 > $O/configs_bf16x2.txt 2>&1
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_graph_x2 -- python $ROOT/bench.py --precision bf16x2 --its 200 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-profile --no-other-input --no-alt-precision --no-other-configs > $O/graph_its200_bf16x2.json 2>/dev/null )
+python scripts/timeline_from_trace.py $(ls $O/prof_graph_x2/*/*kernel_trace.csv) 100 > $O/timeline_iteration_bf16x2.txt 2>&1
+cp $O/prof_graph_x2/*/*kernel_stats.csv $O/graph_its200_bf16x2_kernel_stats.csv
+rm -rf $O/prof_graph_x2
 rm -rf $O/prof_graph_x3
 rm -rf $O/pmc_f $O/pmc_w $O/pmc_f1 $O/pmc_w1 $O/pmc_kernels/sq $O/pmc_kernels/lds $O/pmc_kernels/fetch $O/pmc_kernels/write
 ls $O
