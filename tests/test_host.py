@@ -92,6 +92,21 @@ def test_device_code_has_no_packed_f32_instructions(tmp_path):
         assert total > 1000      # the disassembly really is the kernels
 
 
+def test_precision_names_match_the_header():
+    """`_lib.PRECISIONS` (what `SGACodec(precision=...)`, the driver's `--precision` and bench.py pass into `sga_config`) against the
+    `sga_precision` enum of include/sga_hip.h, incl. the fast mode added in round 4."""
+    with open(os.path.join(ROOT, "include", "sga_hip.h")) as f:
+        hdr = f.read()
+    enum = dict((k, int(v)) for k, v in re.findall(r"SGA_PRECISION_(\w+)\s*=\s*(\d+)", hdr))
+    assert enum == {"DEFAULT": 0, "F32_MFMA": 1, "BF16X3": 2, "BF16X2": 3}
+    assert _lib.PRECISIONS == {"default": 0, "f32": 1, "bf16x3": 2, "bf16x2": 3}
+    for name in ("f32", "bf16x3", "bf16x2"):
+        a = driver.parse_args(["--num_filters", "192", "compress", "--precision", name, "run-lmbda=0.04-x", "in.npy"])
+        assert a.precision == name
+    with pytest.raises(SystemExit):
+        driver.parse_args(["compress", "--precision", "tf32", "run-lmbda=0.04-x", "in.npy"])
+
+
 def test_one_hip_runtime_in_the_process():
     """Loading the library (even before anyone imported torch, as build() does) must leave ONE
     libamdhip64 mapped: torch's bundled copy.  Two copies gave SGA_ERR_NO_DEVICE on a GPU box."""
