@@ -1223,9 +1223,11 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
   if (a.bm == 256) wm = 4;
   if (a.bm == 256 && a.x3 && a.x3w4 && !a.post) { wm = 2; tm = 4; }
   if (a.bm == 64) tm = 1;
-  snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%s,%d>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
+  // the symbol as rocprofv3 prints it, spaces removed (profiles/*_kernel_stats.csv, *_pmc_traffic.json); the 7th argument is the
+  // precision: 0 = f32 MFMA, 1 = bf16x3, 2 = bf16x2
+  snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%d,%d>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
            a.smallc ? "true" : "false",
-           (a.x3 && !a.smallc && bn != 32) ? ((a.x3 == 2 && a.pro == PRO_NONE) ? "x2" : "true") : "false",
+           (a.x3 && !a.smallc && bn != 32) ? ((a.x3 == 2 && a.pro == PRO_NONE) ? 2 : 1) : 0,
            a.post ? (a.post_p ? 2 : 1) : (a.lowfoot && a.bm == 64 && bn == 192 ? 3 : 0));
 }
 

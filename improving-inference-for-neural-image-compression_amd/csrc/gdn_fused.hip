@@ -483,8 +483,8 @@ int gdn_tile_rows(int C, long long M, int pro) {
 void gdn_kernel_name(const GdnArgs& a, char* out, int len) {
   int wm, wn;
   pick_shape(a.C, a.M, a.pro == GDN_PRO_CONV3, wm, wn);
-  if (a.x3 && a.wx3) snprintf(out, len, "gdn_tile_kernel<%d,%d,%d,%d,%d,x3>", a.C / 32, wm, wn, a.mode, a.pro);
-  else snprintf(out, len, "gdn_tile_kernel<%d,%d,%d,%d,%d>", a.C / 32, wm, wn, a.mode, a.pro);
+  // the symbol as rocprofv3 prints it, spaces removed (profiles/*_kernel_stats.csv, *_pmc_traffic.json)
+  snprintf(out, len, "gdn_tile_kernel<%d,%d,%d,%d,%d,%s>", a.C / 32, wm, wn, a.mode, a.pro, (a.x3 && a.wx3) ? "true" : "false");
 }
 
 int launch_gdn_tile(const GdnArgs& a, hipStream_t s) {

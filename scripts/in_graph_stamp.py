@@ -14,7 +14,7 @@ C, B, H, W = 192, 8, 256, 256
 codec = SGACodec(sga_amd.make_synthetic_weights(C, 0), C, B, H, W)
 x = torch.rand(B, H, W, 3, generator=torch.Generator().manual_seed(1000)).cuda()
 codec.run(x, 0.01, its=50, metrics=False)
-codec.profile_graph_begin(os.environ.get("SYM", "conv_mfma_kernel<2,3,4,2,0,false,false,1>"))
+codec.profile_graph_begin(os.environ.get("SYM", "conv_mfma_kernel<2,3,4,2,0,false,0,1>"))
 codec.run(x, 0.01, its=300, metrics=False)
 g = codec.profile_graph_end()
 print("%%.1f" %% (1e3 * g["ms_total"] / max(g["launches"], 1)))

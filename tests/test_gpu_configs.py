@@ -70,6 +70,37 @@ def test_step_at_config_shape(C, H, W, f64, sb, precision, gpu_out_dir):
     codec.close()
 
 
+@pytest.mark.parametrize("C,H,W,f64", [(192, 512, 768, True), (256, 1200, 1200, False), (256, 96, 80, True)])
+def test_step_at_config_shape_bf16x2(C, H, W, f64, gpu_out_dir):
+    """The fast precision mode (two bf16 planes per convolution operand) at the cfg-3 / cfg-4 shapes, incl. the 256-wide tiles of
+    num_filters = 256: one evaluation vs the oracle with the mode's own bounds (gy 2e-3, gz 2e-2 of their maxima: 16-bit
+    operands, and gz passes through 1 / sigma of the raw-sigma conditional), the logged objective to 1e-4, and a short run that is
+    reproducible and improves the objective."""
+    from sga_amd.codec import SGACodec, metrics_to_dict
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    x = np.random.RandomState(1).rand(1, H, W, 3).astype(np.float32)
+    sb = 0.0 if f64 else 0.11      # Tecnick size has only the float32 oracle: bounded sigma there (see the test above)
+    orc = SGAOracle(w, dtype=torch.float64 if f64 else torch.float32, scale_bound=sb)
+    codec = SGACodec(w, C, 1, H, W, precision="bf16x2", scale_bound=sb)
+    yo, zo = SGAOracle(w).encode(x)
+    seed, it, T, lmbda = 9, 3, 0.3, 0.05
+    u_y = philox.sga_uniforms(yo.numel(), it, 0, seed)
+    u_z = philox.sga_uniforms(zo.numel(), it, 1, seed)
+    want = orc.step(x, yo, zo, T, u_y, u_z, lmbda)
+    got = codec.step_grads(x, yo.numpy(), zo.numpy(), T, lmbda, seed=seed, it=it)
+    errs = dict(gy=rel_err(got["gy"].cpu().numpy(), want["gy"].numpy()), gz=rel_err(got["gz"].cpu().numpy(), want["gz"].numpy()),
+                rd_loss=abs(float(got["rd_loss"]) / float(want["rd_loss"]) - 1))
+    report(gpu_out_dir, test="config_step_bf16x2", C=C, H=H, W=W, scale_bound=sb, **errs)
+    assert errs["gy"] < 2e-3 and errs["gz"] < 2e-2 and errs["rd_loss"] < 1e-4, errs
+    a = codec.run(x, lmbda, its=40, t0=10, annealing_rate=0.02, seed=2)
+    b = codec.run(x, lmbda, its=40, t0=10, annealing_rate=0.02, seed=2)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    m, m0 = metrics_to_dict(a[2]), metrics_to_dict(codec.run(x, lmbda, its=0)[2])
+    assert np.isfinite(m["est_bpp"]).all() and np.isfinite(m["psnr"]).all()
+    assert (lmbda * m["mse"] + m["est_bpp"] < lmbda * m0["mse"] + m0["est_bpp"]).all()
+    codec.close()
+
+
 # (B, H, W) chosen so that the launch planner of csrc/sga_api.hip (conv_launch / pick_ksplit: tile height 64 / 128 / 256 rows by
 # the number of 128-row tiles, split-K by grid efficiency, IGDN post-phase only in unsplit launches, XCD-aware tile order only
 # when the tile count is a multiple of 8, phase pairing only when the whole 4-phase grid is resident) takes a different branch
