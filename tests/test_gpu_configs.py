@@ -130,7 +130,7 @@ def relu_kink_margin(orc64, z_tilde):
     summation ORDER -- split-K count, tile width -- in any float32 implementation, and its whole contribution (0.1-0.5 % of the
     ~100 gz elements in its receptive field) appears or disappears.  Found by this sweep at (192, 4, 256, 256): unit (channel
     249, 13, 12) of image 0 sits at 3e-6 of the rms; the f32 path deviates 4.8e-4 there with split-K targets 128 / 384 / 768 and
-    1e-5 with 256 / 512 or 96-wide tiles (scripts/gz_probe2.py), the float64 oracle with that unit's mask flipped agrees."""
+    1e-5 with 256 / 512 or 96-wide tiles (tests/tools/gz_probe2.py), the float64 oracle with that unit's mask flipped agrees."""
     import torch.nn.functional as F
     from oracle.sga_oracle import _nchw
     t = _nchw(torch.as_tensor(z_tilde, dtype=torch.float64))

@@ -1,7 +1,7 @@
 """GPU box: the gz error of one SGA evaluation vs the float64 oracle at 256x256, C = 192, by batch size and launch knob --
 is a 5e-4 deviation (tests/test_gpu_configs.py::test_step_across_launch_plans[192-4-256-256]) the plan or the conditioning?"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch, sga_amd
 from oracle import philox
 from oracle.sga_oracle import SGAOracle

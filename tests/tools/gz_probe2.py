@@ -1,6 +1,6 @@
 """GPU box: where the 4.8e-4 gz deviation of the f32 path at B = 4, 256x256 sits and which launch knob moves it."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch, sga_amd
 from oracle import philox
 from oracle.sga_oracle import SGAOracle

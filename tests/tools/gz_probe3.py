@@ -2,7 +2,7 @@
 shapes, split-K target swept through the laboratory build's SGA_MAIN_TARGET, vs float64 autograd: which layer / split
 produces the 4.8e-4 gz deviation of the step?"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch, sga_amd
 from oracle.sga_oracle import SGAOracle
 from sga_amd.codec import SGACodec
