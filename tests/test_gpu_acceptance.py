@@ -56,6 +56,15 @@ def test_full_run_at_the_benchmarked_geometry_is_consistent_with_the_oracle(gpu_
     assert abs(rep["mean_d_psnr"]) <= TOL_PSNR
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x2"])
+def test_full_run_at_the_benchmarked_geometry_bf16_modes(gpu_out_dir, precision):
+    """The same consistency check (see above: this set does not resolve 1e-3 bpp; PSNR it does) for the two bf16-pipe modes
+    at the geometry `alt_precision` / `fast_precision` of bench.py are timed on: the 256-row X3 / X2 instances with the IGDN
+    post-phase and the two-stream graph over 2000 steps."""
+    rep = _acceptance(gpu_out_dir, "full_run_oracle_cfg2.json", precision, "_" + precision)
+    assert abs(rep["mean_d_psnr"]) <= TOL_PSNR
+
+
 @pytest.mark.parametrize("golden", ["full_run_oracle.json", "full_run_oracle_fitted.json"])
 def test_full_run_bf16x3_mode_within_north_star_tolerance(gpu_out_dir, golden):
     """The opt-in precision mode (exact 3 x bf16 operand split; `alt_precision` of bench.py, not the
