@@ -273,6 +273,12 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   const int blocks = a.nphase * tiles;
   static const int main_target = LAB_ENV("SGA_MAIN_TARGET") ? atoi(LAB_ENV("SGA_MAIN_TARGET")) : 512;   // experiments
   int target = a.bm == 256 ? 256 : main_target;      // ~512 workgroups of (nearly) equal K length (tuned at cfg 2); 256-row: one per CU
+  // Small grids (<= 64 tiles before the split: the 16^2 ... 32^2 stages of a single 256^2 image) gain nothing from a 512-way
+  // grid -- their K walk is already 2-3 steps per workgroup and every extra slab is summed by the consumer -- so they aim at one
+  // workgroup per CU (measured per layer at B = 1: gs0.* 19 -> 17 / 30 -> 26 us, igdn0.* 28 -> 24 / 27 -> 21; the larger layers
+  // lose with that target and keep 512; profiles/r04_b1_split_targets_by_layer.txt)
+  static const int small_tiles = LAB_ENV("SGA_SMALL_TILES") ? atoi(LAB_ENV("SGA_SMALL_TILES")) : 64;      // 0: rule off (experiments)
+  if (a.bm != 256 && blocks <= small_tiles) target = 256;
   if (h->in_hyper && h->side_target > 0) target = h->side_target;   // hyper branch (whichever stream it runs on: the
                                                                      // split decides the summation order, i.e. result bits)
   const int bn = a.Npad / a.ntiles_n;
