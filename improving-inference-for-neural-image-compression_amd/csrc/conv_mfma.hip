@@ -20,6 +20,8 @@
 #include <atomic>
 #include <cstdio>
 
+#include <type_traits>
+
 #include "sga_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -894,18 +896,21 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
       long long px[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) px[k] = rowpix[h * HR + m4 * 32 + er + 8 * k];
-      auto emit = [&](float* dst) {                  // the block, row-major, 16 bytes per lane
+      auto emit = [&](float* dst, auto nt_c) {       // the block, row-major, 16 bytes per lane
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
           for (int j = 0; j < PTN; ++j) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(rb0 + k * 8 * TP + j * 32);
-            if (px[k] >= 0)
-              *reinterpret_cast<f32x4*>(dst + (size_t)px[k] * a.out_cs + a.out_coff + n2 * PTN * 32 + j * 32 + ec * 4) = v;
+            if (px[k] >= 0) {
+              f32x4* const q = reinterpret_cast<f32x4*>(dst + (size_t)px[k] * a.out_cs + a.out_coff + n2 * PTN * 32 + j * 32 + ec * 4);
+              if constexpr (decltype(nt_c)::value) __builtin_nontemporal_store(v, q);
+              else *q = v;
+            }
           }
       };
       if (a.out) {                                   // u (null: the backward pass forms it as v / s)
-        emit(a.out);
+        emit(a.out, std::false_type{});
         __builtin_amdgcn_wave_barrier();
       }
 #pragma unroll
@@ -918,7 +923,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
           *e = *e * sv;                                         // v = u * s, in place
         }
       __builtin_amdgcn_wave_barrier();
-      emit(a.post_v);                                // v
+      emit(a.post_v, std::integral_constant<bool, (SGA_NT & 8) != 0>{});      // v
       __builtin_amdgcn_wave_barrier();
       // ---- the NEXT layer's products while v is on chip (C -> 3 transposed convolution, nn_models.py:60-63) ----
       // P[pixel, (ky, kx, c)] = v[pixel, :] . W3[ky, kx, :, c] for all 25 x 3 (padded to 80) kernel columns: a third
@@ -982,7 +987,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
         for (int reg = 0; reg < 16; ++reg)
           cb[((reg & 3) + 8 * (reg >> 2)) * TP + tn * 32] = acc2[tn][reg];   // s (kept where n was)
       __builtin_amdgcn_wave_barrier();
-      emit(a.post_s);                                // s
+      emit(a.post_s, std::integral_constant<bool, (SGA_NT & 4) != 0>{});      // s (not read again before the backward pass)
       lds_barrier();                                 // the tile is rewritten by the next part
     }
     SGA_PROBE_END();

@@ -49,7 +49,13 @@ __global__ __launch_bounds__(GNT, 4) void deconv3_gemm_kernel(const float* __res
     if (row >= M) row = M - 1;                     // clamped re-read, discarded at the store
     const float* src = in + (size_t)row * C + g * 4;
 #pragma unroll
-    for (int q = 0; q < CQ; ++q) dst[q] = *reinterpret_cast<const f32x4*>(src + q * 16);
+    for (int q = 0; q < CQ; ++q) {
+#if SGA_NT & 16
+      dst[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + q * 16));
+#else
+      dst[q] = *reinterpret_cast<const f32x4*>(src + q * 16);
+#endif
+    }
   };
   for (; rb < nrb; rb += stride) {
     load_rows(rb, a_cur);

@@ -270,8 +270,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
       if constexpr (PRO == GDN_PRO_CONV3) t[slot][kc] = *reinterpret_cast<const f32x4*>(tp + kr * R * TP + kc * CW * 4);
       else t[slot][kc] = ld4(a.src + ro + kc * CW * 4);
       if constexpr (MODE == GDN_IGDN_BWD) {
+#if SGA_IGDN_NT & 1      // read once by this launch, dead afterwards (round 5)
+        uu[slot][kc] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((a.v ? a.v : a.u) + ro + kc * CW * 4));
+        ss[slot][kc] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.s + ro + kc * CW * 4));
+#else
         uu[slot][kc] = ld4((a.v ? a.v : a.u) + ro + kc * CW * 4);
         ss[slot][kc] = ld4(a.s + ro + kc * CW * 4);
+#endif
       }
     }
   };
@@ -397,7 +402,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
         const size_t e = ro + kc * CW * 4;
         const f32x4 n = *reinterpret_cast<const f32x4*>(tp + kr * R * TP + kc * CW * 4);
         if constexpr (MODE == GDN_IGDN_BWD) {
+#if SGA_IGDN_NT & 2
+          __builtin_nontemporal_store(e1[k] + e2[k] * n, reinterpret_cast<f32x4*>(a.out + e));
+#else
           *reinterpret_cast<f32x4*>(a.out + e) = e1[k] + e2[k] * n;
+#endif
         } else {
           const f32x4 nb = n + betav[kc];
           f32x4 sq, v;
@@ -405,13 +414,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gdn_tile_kernel(const GdnArgs
           for (int x = 0; x < 4; ++x) sq[x] = sqrtf(nb[x]);
           if constexpr (MODE == GDN_IGDN_FWD) {
             v = e1[k] * sq;
-            if (a.s_out_p) *reinterpret_cast<f32x4*>(a.s_out_p + e) = sq;
+            if (a.s_out_p) {
+#if SGA_NT & 32
+              __builtin_nontemporal_store(sq, reinterpret_cast<f32x4*>(a.s_out_p + e));
+#else
+              *reinterpret_cast<f32x4*>(a.s_out_p + e) = sq;
+#endif
+            }
           } else {
 #pragma unroll
             for (int x = 0; x < 4; ++x) v[x] = e1[k][x] / sq[x];
           }
           if (a.u_out) *reinterpret_cast<f32x4*>(a.u_out + e) = e1[k];
+#if SGA_NT & 64
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + e));
+#else
           *reinterpret_cast<f32x4*>(a.out + e) = v;
+#endif
         }
       }
     }
@@ -480,7 +499,20 @@ int gdn_tile_rows(int C, long long M, int pro) {
   return wm * 32;
 }
 
+// the persistent wave-specialised kernel (igdn_bwd_ws.hip) takes igdn2.bwd-shaped launches: backward with the gradient
+// convolution in it, f32 contraction, and enough tiles for its pipeline (>= 2 per CU)
+static bool use_ws(const GdnArgs& a) {
+#ifdef SGA_EXPERIMENTS      // laboratory build only (it lost in the iteration: DESIGN_EXPERIMENTS.md A.10); scripts/r05/igdn_ws_bench.hip defines it too
+  if (!a.ws || !igdn_bwd_ws_supported(a)) return false;
+  return a.ws == 2 || (a.M + 63) / 64 >= 512;
+#else
+  (void)a;
+  return false;
+#endif
+}
+
 void gdn_kernel_name(const GdnArgs& a, char* out, int len) {
+  if (use_ws(a)) { snprintf(out, len, "igdn_bwd_ws_kernel<%d>", a.C / 32); return; }
   int wm, wn;
   pick_shape(a.C, a.M, a.pro == GDN_PRO_CONV3, wm, wn);
   // the symbol as rocprofv3 prints it, spaces removed (profiles/*_kernel_stats.csv, *_pmc_traffic.json)
@@ -488,6 +520,9 @@ void gdn_kernel_name(const GdnArgs& a, char* out, int len) {
 }
 
 int launch_gdn_tile(const GdnArgs& a, hipStream_t s) {
+#ifdef SGA_EXPERIMENTS
+  if (use_ws(a)) return launch_igdn_bwd_ws(a, s);
+#endif
   int wm, wn;
   pick_shape(a.C, a.M, a.pro == GDN_PRO_CONV3, wm, wn);
   switch (a.C / 32) {

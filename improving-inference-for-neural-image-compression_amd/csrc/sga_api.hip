@@ -20,6 +20,7 @@ constexpr int BM_TILE = 128;
 struct PackedConv {
   float* w = nullptr;   // device [nslab][Npad][Kc]
   unsigned short* w3 = nullptr;   // device bf16x3 planes [nslab][Npad][Kc/32][3][32] (precision mode bf16x3)
+  float* wf = nullptr;  // the same matrix in MFMA fragment order (pack_frag): B operands loaded straight into registers
   int Kc = 0;           // contiguous K per slab row (C_in of the GEMM)
   int N = 0;            // real output channels
   int Npad = 0, bn = 0;
@@ -84,6 +85,12 @@ struct sga_handle {
   struct ClkSlot { char name[96]; int grid; };
   std::vector<ClkSlot> clk_slots;
   unsigned* ticket = nullptr;      // k_step_boundary's last-workgroup counter (zero between launches)
+  unsigned* ws_sched = nullptr;    // igdn_bwd_ws_kernel's shared tile counter + exit counter (zero between launches)
+  int igdn_ws = 0;                 // SGA_IGDN_WS (laboratory build): 0 = igdn2.bwd on gdn_tile_kernel (default), 1 = on the persistent wave-specialised kernel of
+                                   //   igdn_bwd_ws.hip when the launch has >= 2 tiles per CU, 2 = whenever its shape is supported (tests).
+                                   //   Round 5: alone 144.5 against 148.3 us at cfg 2, but +20 us in the iteration -- its one 150-KB workgroup per
+                                   //   CU leaves no room for the hyper branch's kernels beside it (DESIGN_EXPERIMENTS.md A.10)
+  bool igdn_ws_dynamic = true;     // SGA_IGDN_WS_SCHED=static: tiles b, b + grid, ... instead of the shared counter
   bool fused_boundary = true;      // SGA_FUSED_BOUNDARY=0: Adam, relaxation and finalize as three launches
   float* gs3_halo_w = nullptr;   // C->3 layer packed for deconv3.hip: [C/32][9][16][32]
   bool gs3_generic = false;      // SGA_GS3_GENERIC=1: use the generic gather-GEMM for the C->3 layer
@@ -617,6 +624,24 @@ bool bn96_as_192(const sga_handle* h) {
   return (!h->x3 || h->x3_variants) && !(e && e[0] == '0');
 }
 
+// B operand in MFMA fragment order.  `w` is [nslab][Npad][Kc] (rows = output channels, K contiguous); step Q = slab * (Kc / 8)
+// + q covers k = q*8 .. q*8+7 of its slab; lane (half = lane >> 5, col = lane & 31) of the 32x32x2 MFMA numbered r (0..3) of
+// that step multiplies row nb*32 + col at k = q*8 + half*4 + r -- so one wave-load of 16 bytes per lane is 1 KB contiguous:
+//   f[((Q * NB + nb) * 64 + lane) * 4 + r] = w[(slab * Npad + nb*32 + col) * Kc + q*8 + half*4 + r],  NB = N / 32
+int pack_frag(sga_handle* h, PackedConv& pc, const std::vector<float>& w) {
+  if (pc.N % 32 != 0 || pc.Kc % 8 != 0) return SGA_OK;
+  const int NB = pc.N / 32, qs = pc.Kc / 8;
+  std::vector<float> f((size_t)pc.nslab * qs * NB * 256, 0.f);
+  for (int sl = 0; sl < pc.nslab; ++sl)
+    for (int q = 0; q < qs; ++q)
+      for (int nb = 0; nb < NB; ++nb)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int r = 0; r < 4; ++r)
+            f[((((size_t)sl * qs + q) * NB + nb) * 64 + lane) * 4 + r] =
+                w[((size_t)sl * pc.Npad + nb * 32 + (lane & 31)) * pc.Kc + q * 8 + (lane >> 5) * 4 + r];
+  return upload(h, &pc.wf, f.data(), f.size());
+}
+
 // GEMM with N = co, K = ci:  w[t][co][ci] = K[t][ci][co]   (forward of any conv)
 int pack_fwd(sga_handle* h, PackedConv& pc, const float* K, int taps, int ci, int co, int epi) {
   pc.Kc = ci; pc.N = co; pc.nslab = taps;
@@ -656,6 +681,9 @@ int pack_gdn(sga_handle* h, PackedConv& pc, const float* gamma, int C, bool back
   for (int i = 0; i < C; ++i)
     for (int k = 0; k < C; ++k)
       w[(size_t)i * C + k] = backward ? gamma[(size_t)i * C + k] : gamma[(size_t)k * C + i];
+#ifdef SGA_EXPERIMENTS
+  if (backward) SGACHK(pack_frag(h, pc, w));      // igdn_bwd_ws.hip (laboratory build)
+#endif
   return upload_packed(h, pc, w);
 }
 
@@ -703,6 +731,9 @@ int pack_smallc(sga_handle* h, PackedConv& pc, const float* K, int C, bool bwd) 
         }
       }
     }
+#ifdef SGA_EXPERIMENTS
+  if (bwd) SGACHK(pack_frag(h, pc, w));           // igdn_bwd_ws.hip (laboratory build)
+#endif
   return upload_packed(h, pc, w, false);
 }
 
@@ -906,7 +937,11 @@ int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float*
     g.C = pc.N; g.mode = GDN_IGDN_BWD; g.pro = gpad ? GDN_PRO_CONV3 : GDN_PRO_LOAD;
     g.M = (long long)B * Hh * Ww;
     gdn_source(g, g_v, d);
-    if (gpad) { g.pad = gpad; g.wc = pc3->w; g.Hg = Hh; g.Wg = Ww; g.Hp = Hp; g.Wp = Wp; }
+    if (gpad) {
+      g.pad = gpad; g.wc = pc3->w; g.Hg = Hh; g.Wg = Ww; g.Hp = Hp; g.Wp = Wp;
+      // the persistent wave-specialised kernel (igdn_bwd_ws.hip; f32 contraction in every precision mode)
+      g.wf = pc.wf; g.wcf = pc3->wf; g.ws = h->igdn_ws; g.sched = h->igdn_ws_dynamic ? h->ws_sched : nullptr;
+    }
     g.w = pc.w; g.wx3 = pc.w3; g.x3 = (h->x3 && h->x3_variants) ? 1 : 0; g.u = u; g.s = s; g.out = g_u; g.v = v;
     g.flops = 2.0 * B * Hh * Ww * (double)pc.Kc * pc.N + (gpad ? 2.0 * B * Hh * Ww * 75.0 * pc.N : 0.0);
     return gdn_launch(h, g, st);
@@ -1584,6 +1619,9 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     TRY(dev_alloc(h, &p, 17 * 128));      // k_step_boundary: top counter + 16 group counters, one cache line each
     if (hipMemset(p, 0, 17 * 128) != hipSuccess) return fail(SGA_ERR_HIP);
     h->ticket = (unsigned*)p;
+    TRY(dev_alloc(h, &p, 256));
+    if (hipMemset(p, 0, 256) != hipSuccess) return fail(SGA_ERR_HIP);
+    h->ws_sched = (unsigned*)p;
   }
   {
     void* p = nullptr;
@@ -1591,7 +1629,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     if (hipMemset(p, 0, 256) != hipSuccess) return fail(SGA_ERR_HIP);
     h->zeros = (float*)p;
 #ifdef SGA_CLOCK_PROBE
-    if (const char* e = LAB_ENV("SGA_CLOCK_PROBE")) {
+    if (const char* e = PROBE_ENV("SGA_CLOCK_PROBE")) {      // (a PROBE=1 build is not an EXPERIMENTS=1 build: not LAB_ENV)
       h->clk_mode = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0);
       if (h->clk_mode) {
         void* q = nullptr;
@@ -1722,6 +1760,10 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->fused_mse = !(env && env[0] == '0');
   env = getenv("SGA_NO_SPLITK");
   h->no_splitk = env && env[0] == '1';
+  env = LAB_ENV("SGA_IGDN_WS");
+  if (env) h->igdn_ws = atoi(env);
+  env = LAB_ENV("SGA_IGDN_WS_SCHED");
+  if (env) h->igdn_ws_dynamic = strcmp(env, "static") != 0;
   env = getenv("SGA_PROFILE_BY_LAYER");
   h->profile_by_layer = env && env[0] == '1';
 #undef TRY
@@ -1737,7 +1779,7 @@ int sga_destroy(sga_handle* h) {
     for (size_t s = 0; s < h->clk_slots.size(); ++s) {
       if (hipMemcpy(t.data(), h->clk_probe + s * (size_t)(6 * 16384), t.size() * sizeof(t[0]), hipMemcpyDeviceToHost) != hipSuccess) break;
       if (strncmp(h->clk_slots[s].name, "gdn:", 4) == 0) {      // raw [grid][8] u64 wall-clock stamps (gdn_fused.hip)
-        if (const char* dir = LAB_ENV("SGA_CLOCK_PROBE_DUMP")) {
+        if (const char* dir = PROBE_ENV("SGA_CLOCK_PROBE_DUMP")) {
           char fn[512];
           snprintf(fn, sizeof(fn), "%s/gdn_slot_%02zu.bin", dir, s);
           if (FILE* f = fopen(fn, "wb")) { fwrite(t.data(), sizeof(t[0]), 8 * (size_t)h->clk_slots[s].grid, f); fclose(f); }
@@ -1751,7 +1793,7 @@ int sga_destroy(sga_handle* h) {
         wmin = std::min(wmin, (double)t[6 * i + 1]); wmax = std::max(wmax, (double)t[6 * i + 1]);
       }
       const int g = h->clk_slots[s].grid;
-      if (const char* dir = LAB_ENV("SGA_CLOCK_PROBE_DUMP")) {      // raw [grid][6] u64: K-loop cycles, K-loop wall ticks, hw_id | xcc_id << 32, wall at K-loop start, at entry, at exit
+      if (const char* dir = PROBE_ENV("SGA_CLOCK_PROBE_DUMP")) {      // raw [grid][6] u64: K-loop cycles, K-loop wall ticks, hw_id | xcc_id << 32, wall at K-loop start, at entry, at exit
         char fn[512];
         snprintf(fn, sizeof(fn), "%s/clk_slot_%02zu.bin", dir, s);
         if (FILE* f = fopen(fn, "wb")) { fwrite(t.data(), sizeof(t[0]), 6 * (size_t)g, f); fclose(f); }

@@ -15,6 +15,13 @@
 #define LAB_ENV(name) (static_cast<const char*>(nullptr))
 #endif
 
+// Knobs of the measurement build (make PROBE=1; not an EXPERIMENTS=1 build, so LAB_ENV would never see them -- ADVICE r4)
+#ifdef SGA_CLOCK_PROBE
+#define PROBE_ENV(name) getenv(name)
+#else
+#define PROBE_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 // Per-step scalars live in DEVICE memory so that one captured hipGraph of the step
 // sequence can be replayed for every SGA iteration (sga.py:210-215): a 1-thread kernel
 // advances `it` and refreshes T / lr_t from tables at the head of each replay.
@@ -136,6 +143,16 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len);
 // GDN / IGDN tile kernel (gdn_fused.hip): prologue (slab sum | 3-channel conv) + resident-operand
 // C x C contraction + epilogue in one launch
 // ---------------------------------------------------------------------------------------
+// Cache policy of the big streams (compile time: behind a run-time flag the compiler merges the two forms into plain accesses).
+// Non-temporal = the line is not kept in L1 / L2 for this access: right for data that is read once by a launch, or written and not
+// read again for a long time.  Bits: 1 igdn*.bwd read v (u), s | 2 igdn*.bwd write g_u | 4 IGDN post-phase of a convolution writes s
+// | 8 ... writes v | 16 the C -> 3 GEMM reads its input | 32 gdn_tile_kernel forward writes s | 64 ... writes v
+// Measured in the cfg-2 iteration (scripts/r05/s09_nt_masks.sh, profiles/r05_nt_masks.txt): 15 = bits 1|2|4|8 -5 us (1784 -> 1778),
+// the others within the noise; 15 ships.
+#ifndef SGA_NT
+#define SGA_NT 15
+#endif
+#define SGA_IGDN_NT (SGA_NT & 3)
 enum GdnMode { GDN_IGDN_FWD = 0, GDN_GDN_FWD = 1, GDN_IGDN_BWD = 2 };
 enum GdnPrologue { GDN_PRO_LOAD = 0, GDN_PRO_CONV3 = 1 };
 struct GdnArgs {
@@ -158,6 +175,11 @@ struct GdnArgs {
   float* u_out;            // forward: T written back (needed when T was assembled here), or null
   double flops;            // algorithmic flops (profiling only)
   int prio;                // wave priority (experiment)
+  // persistent wave-specialised form of the backward pass with the gradient-convolution prologue (igdn_bwd_ws.hip):
+  const float* wf;         // gamma in MFMA fragment order [K/8][C/32][64 lanes][4] (pack_frag), or null
+  const float* wcf;        // the 3-channel kernel `wc` in the same order [12][C/32][64][4], or null
+  unsigned* sched;         // two zeroed counters (shared tile counter, exit counter), or null: tiles b, b + grid, ...
+  int ws;                  // 0: gdn_tile_kernel; 1: the persistent kernel when the launch has at least two tiles per CU; 2: whenever supported
 #ifdef SGA_CLOCK_PROBE
   unsigned long long* clk; // measurement build: per workgroup 8 x u64 = wall clock (100 MHz) at entry, after the prologue,
                            //   after the fill, after the contraction, at exit, hw_id | xcc_id << 32
@@ -166,6 +188,9 @@ struct GdnArgs {
 int launch_gdn_tile(const GdnArgs& a, hipStream_t stream);
 int gdn_tile_rows(int C, long long M, int pro);
 void gdn_kernel_name(const GdnArgs& a, char* out, int len);
+// igdn_bwd_ws.hip
+bool igdn_bwd_ws_supported(const GdnArgs& a);
+int launch_igdn_bwd_ws(const GdnArgs& a, hipStream_t stream);
 
 // C -> 3 transposed 5x5/2 conv, halo-tiled (deconv3.hip); w packed [C/32][9 taps][16][32]
 int launch_deconv3_halo(const float* in, const float* w, const float* bias, float* out, int B,

@@ -279,3 +279,62 @@ def test_lab_build_equals_the_product_build():
     a, b = prod.run(x, 0.01, its=120, seed=1), lab.run(x, 0.01, its=120, seed=1)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     prod.close(); lab.close()
+
+
+# the last synthesis stage's IGDN data-gradient (with the C -> 3 layer's data-gradient in it) as the persistent,
+# wave-specialised kernel of round 5 (csrc/igdn_bwd_ws.hip) against the tile kernel it replaces (csrc/gdn_fused.hip):
+# same 32 x 96 blocks per wave, same K order, same elementwise expressions -> BIT-equal.  The persistent kernel is a
+# LABORATORY alternative (libsga_hip_lab.so; it is faster alone and slower inside the iteration, DESIGN_EXPERIMENTS.md A.10):
+# SGA_IGDN_WS=2 forces it at every supported shape, =1 from two tiles per CU, =0 (default) is the tile kernel.
+WS_SHAPES = [(192, 8, 256, 256),          # cfg 2: 2048 tiles, eight per CU
+             (192, 1, 256, 256),          # 256 tiles: one per workgroup (no steady state: prologue -> one phase -> drain)
+             (192, 1, 64, 48),            # 12 tiles: a grid smaller than the chip
+             (192, 2, 200, 264),          # ragged: latents 13 x 17, crops, a partial last tile
+             (64, 2, 64, 64), (64, 1, 50, 70), (128, 3, 37, 41), (128, 2, 512, 512),
+             (192, 3, 512, 768)]          # Kodak, three images: 9216 tiles, 36 per CU
+
+
+@pytest.mark.parametrize("C,B,H,W", WS_SHAPES)
+@pytest.mark.parametrize("sched", ["dynamic", "static"])
+def test_persistent_igdn_bwd_equals_the_tile_kernel(C, B, H, W, sched, monkeypatch):
+    """nn_models.py:59-63 backward (its part of sga.py:164)."""
+    from sga_amd.codec import SGACodec
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    monkeypatch.setenv("SGA_IGDN_WS_SCHED", sched)
+    monkeypatch.setenv("SGA_IGDN_WS", "2")
+    ws = SGACodec(w, C, B, H, W, lab=True)
+    monkeypatch.setenv("SGA_IGDN_WS", "0")
+    tile = SGACodec(w, C, B, H, W, lab=True)
+    x = np.random.RandomState(C + H).rand(B, H, W, 3).astype(np.float32)
+    y, z = tile.encode(x)
+    ws.profile_begin(); ra = ws.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5); names = [k["name"] for k in ws.profile_end()]
+    rb = tile.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    assert any(n.replace(" ", "").startswith("igdn_bwd_ws_kernel<%d>" % (C // 32)) for n in names), names
+    assert float(ra["gy"].abs().max()) > 0
+    assert torch.equal(ra["gy"], rb["gy"]) and torch.equal(ra["gz"], rb["gz"]) and ra["rd_loss"] == rb["rd_loss"]
+    # repeated launches (the shared tile counter must be back at zero) and the graph replay
+    for _ in range(3):
+        rc = ws.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+        assert torch.equal(rc["gy"], rb["gy"])
+    its = 8 if H * W > 40000 else 20
+    a = ws.run(x, 0.01, its=its, seed=1); b = tile.run(x, 0.01, its=its, seed=1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    ws.close(); tile.close()
+
+
+def test_persistent_igdn_bwd_with_stored_u_equals_the_tile_kernel(monkeypatch):
+    """SGA_KEEP_U=1 (laboratory): the IGDN stores its input and the data-gradient reads it instead of forming v / s."""
+    from sga_amd.codec import SGACodec
+    C, B, H, W = 192, 2, 256, 256
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    monkeypatch.setenv("SGA_KEEP_U", "1")
+    monkeypatch.setenv("SGA_IGDN_WS", "2")
+    ws = SGACodec(w, C, B, H, W, lab=True)
+    monkeypatch.setenv("SGA_IGDN_WS", "0")
+    tile = SGACodec(w, C, B, H, W, lab=True)
+    x = np.random.RandomState(5).rand(B, H, W, 3).astype(np.float32)
+    y, z = tile.encode(x)
+    ra = ws.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    rb = tile.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    assert torch.equal(ra["gy"], rb["gy"]) and torch.equal(ra["gz"], rb["gz"])
+    ws.close(); tile.close()

@@ -10,6 +10,7 @@ float16-representable values, as tests/golden/fitted_weights_c64.npz (+ its dige
 fitted_weights_c64.json).  Deterministic inputs; the stored file, not a re-run of this script, defines the model.
 
     python tests/tools/fit_weights.py [steps=4000]        # ~10 min on 3 cores
+    FIT_C=192 NTHREADS=4 python tests/tools/fit_weights.py 4000   # -> fitted_weights_c192.npz (round 5)
     python tests/tools/fit_weights.py 4000 bb             # the mbt2018_bb model (cfg 5: h_a emits mean | logvar, bb_sga.py:69)
                                                           # -> fitted_weights_c64bb.npz, objective = the bits-back ELBO
 """
@@ -27,8 +28,9 @@ import torch
 import sga_amd
 from oracle.sga_oracle import SGAOracle, lower_bound, LIKELIHOOD_BOUND, SCALES_MIN
 
-C, H, W, BATCH, LMBDA = 64, 64, 64, 8, 0.01
-OUT = os.path.join(ROOT, "tests", "golden", "fitted_weights_c64")
+C = int(os.environ.get("FIT_C", "64"))        # FIT_C=192: the north star's width (round 5; ~40 min on 4 cores)
+H, W, BATCH, LMBDA = 64, 64, 8, 0.01
+OUT = os.path.join(ROOT, "tests", "golden", "fitted_weights_c%d" % C)
 
 
 def raw_from_effective(w):
