@@ -18,7 +18,7 @@ LAB_LIB_PATH = os.path.join(_PKG_DIR, "libsga_hip_lab.so")
 PRODUCT_ENV_KNOBS = ("SGA_PRECISION", "SGA_NO_GRAPH", "SGA_NO_OVERLAP", "SGA_NO_SPLITK", "SGA_FORK_NAME", "SGA_FORK_VERBOSE",
                      "SGA_PROFILE_BY_LAYER", "SGA_GRAPH_DROP", "SGA_X3_FORK", "SGA_X3_VARIANTS")
 
-SGA_ABI_VERSION = 3
+SGA_ABI_VERSION = 4
 
 STATUS = {
     0: "SGA_OK", -1: "SGA_ERR_BAD_ARG", -2: "SGA_ERR_BAD_SHAPE", -3: "SGA_ERR_UNSUPPORTED",
@@ -112,6 +112,7 @@ SYMBOLS["sga_profile_end"] = (_I, [_P, C.POINTER(SgaKernelStat), _I, C.POINTER(_
 SYMBOLS["sga_profile_graph_begin"] = (_I, [_P, C.c_char_p])
 SYMBOLS["sga_profile_graph_end"] = (_I, [_P, C.POINTER(SgaKernelStat)])
 SYMBOLS["sga_get_fork_point"] = (_I, [_P, C.c_char_p, _I])
+SYMBOLS["sga_debug_counter"] = (_I, [_P, _I, C.POINTER(C.c_longlong)])
 
 SYMBOLS["sga_ec_y_symbols"] = (_I, [_P, _P, _P, _I64, _P, _I, _I, _I, _P, _P, _P, _P, _P])
 SYMBOLS["sga_ec_z_symbols"] = (_I, [_P, _I64, _I, _P, _P, _P, _P])

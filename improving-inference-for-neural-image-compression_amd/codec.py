@@ -136,7 +136,8 @@ class SGACodec:
                                               _lib.SCHEDULES[schedule]), "sga_set_relaxation")
 
     def set_scale_bound(self, scale_bound: float):
-        """Change the sigma bound of the live handle (drops its cached step graphs)."""
+        """Change the sigma bound of the live handle (the bound is part of the graph cache's key: graphs captured under the
+        other value stay cached; nothing is synchronised or dropped)."""
         self._chk(self.lib.sga_set_scale_bound(self.handle, float(scale_bound)), "sga_set_scale_bound")
         self.scale_bound = float(scale_bound)
 
@@ -575,6 +576,13 @@ class SGACodec:
         buf = C.create_string_buffer(32)
         self._chk(self.lib.sga_get_fork_point(self.handle, buf, 32), "sga_get_fork_point")
         return buf.value.decode()
+
+    def counter(self, which: str) -> int:
+        """Graph-cache counters (sga_debug_counter): "captures", "cached", "evictions", "retired"."""
+        v = C.c_longlong(0)
+        idx = {"captures": 0, "cached": 1, "evictions": 2, "retired": 3}[which]
+        self._chk(self.lib.sga_debug_counter(self.handle, idx, C.byref(v)), "sga_debug_counter")
+        return int(v.value)
 
     # ---- operator surface (unit parity) --------------------------------------------------------
     def layer_fwd(self, layer: str, inp):

@@ -144,6 +144,24 @@ struct sga_handle {
                                    //   graph's root -- synth_branch tick(); SGA_X3_FORK=0: single-stream as in rounds 2-3)
   bool drop_destroy = false;       // drop_graph(): keep a dropped executable graph until sga_destroy (default, "retire") or destroy it at
                                    //   once behind a synchronisation of both streams (SGA_GRAPH_DROP=destroy)
+  // ---- keyed cache of LIVE executable graphs (round 5): one captured iteration per (kind, geometry, relaxation, sigma bound,
+  // stamped) with its timed fork point.  A change of geometry / relaxation / bound SELECTS an entry -- nothing is dropped,
+  // re-captured or re-timed when a shape comes back (a ragged last batch, a service alternating two sizes) -- and entries
+  // live until sga_destroy (the least recently used one is retired only when the cache holds kMaxGraphs).
+  struct GraphKey {
+    int kind;                      // 0: one SGA iteration; 1 / 2: one iteration of bits-back stage 1 / stage 2
+    int B, H, W, relax;
+    float scale_bound;             // crosses to k_gaussian by value, i.e. is baked into the captured launch
+    int stamped;                   // the measurement graph of sga_profile_graph_begin (one kernel carries a stamp pointer)
+    bool operator==(const GraphKey& o) const {
+      return kind == o.kind && B == o.B && H == o.H && W == o.W && relax == o.relax && scale_bound == o.scale_bound && stamped == o.stamped;
+    }
+  };
+  struct GraphEntry { GraphKey key; hipGraphExec_t exec; bool tuned; const char* fork_name; bool stamp_in_graph; unsigned long long used; };
+  std::vector<GraphEntry> graphs;
+  unsigned long long graph_clock = 0;
+  long long n_captures = 0;        // stream captures + instantiations so far (sga_debug_counter)
+  long long n_graph_evictions = 0;
   std::vector<hipGraphExec_t> retired_graphs;   // candidate graphs that lost the timing: destroyed with the handle (experiment:
                                    // destroying them while their sibling is in use crashed the process in the full test suite)
   int tuned_B = 0, tuned_H = 0, tuned_W = 0;   // geometry the last timed choice (tuned_name) was made for: graphs of that
@@ -168,16 +186,11 @@ struct sga_handle {
   Geom geom_zeroed;              // geometry for which xpad/gpad borders are known zero
   bool borders_valid = false;
 
-  // ---- cached step graph ----
-  hipGraphExec_t graph_exec = nullptr;
   bool side_lowfoot = false;       // SGA_SIDE_LOWFOOT=1: the hyper branch's 64-row launches in the 33-KB form (fit beside gs2.bwd)
   int fork_delay_us = 0;           // SGA_FORK_DELAY_US (experiment)
   bool in_hyper = false;           // the launches being enqueued belong to the hyper branch
   int side_target = 384;           // split-K target (workgroups per launch) of the hyper branch (SGA_SIDE_TARGET; 0: the main chain's 512)
   bool side_last = true;           // graph capture: create the hyper branch's nodes after the main chain's (SGA_SIDE_LAST=0: before)
-  int graph_B = 0, graph_H = 0, graph_W = 0, graph_relax = 0;
-  hipGraphExec_t bb_graph[2] = {nullptr, nullptr};   // one iteration of bits-back stage 1 / stage 2
-  int bb_graph_B = 0, bb_graph_H = 0, bb_graph_W = 0;
   int relax = 0, sched = 0;        // sga_set_relaxation
   int use_graph = 1;
 
@@ -1111,7 +1124,7 @@ int hyper_branch_impl(sga_handle* h, const Geom& g, bool with_grad, hipStream_t 
 int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, hipStream_t st,
                  int fork_at = 0, const std::function<int()>* side = nullptr, const std::function<int()>* side2 = nullptr) {
   int launches = 0;
-  bool side_started = false, side2_started = false;
+  bool side_started = false, side2_started = false, fork_pending = false;
   // call before every main-chain launch.  The hyper branch is forked at launch number `fork_at` (SGA_FORK_AT, experiments)
   // or, when the handle names one (fork_name: chosen per geometry by sga_run_steps), right before that launch
   auto tick = [&](const char* name = nullptr) -> int {
@@ -1120,7 +1133,11 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
     // bf16x3 two-stream nondeterminism and moved the failure rate (3 outcomes in 20 replays -> 0 in 20) without being the
     // cause: the cause was the packed-f32 VALU hazard beside bf16 MFMA waves (csrc/Makefile, DESIGN_EXPERIMENTS.md A.8b),
     // which the root fork merely made likelier by co-scheduling the elementwise kernels with the X3 convolutions.
-    const bool here = (h->fork_name ? (name && strcmp(name, h->fork_name) == 0) : launches >= fork_at) && launches >= 1;
+    // (a fork point that NAMES the first launch -- SGA_FORK_NAME=gs0.fwd -- is therefore taken at the second one: `pending`;
+    //  before round 5 it never matched and the step ran serialised)
+    const bool named = h->fork_name ? (name && strcmp(name, h->fork_name) == 0) : launches >= fork_at;
+    if (named && launches == 0) fork_pending = true;
+    const bool here = (named || fork_pending) && launches >= 1;
     if (side && !side_started && here) { side_started = true; SGACHK((*side)()); }
     // second fork point (captured graph only): the branch's BACKWARD half may not start before this launch
     if (side2 && !side2_started && name && h->fork2_name && strcmp(name, h->fork2_name) == 0) { side2_started = true; SGACHK((*side2)()); }
@@ -1358,6 +1375,43 @@ void drop_graph(sga_handle* h, hipGraphExec_t& ex, hipStream_t st = nullptr) {
   ex = nullptr;
 }
 
+constexpr size_t kMaxGraphs = 16;
+
+sga_handle::GraphEntry* find_graph(sga_handle* h, const sga_handle::GraphKey& k) {
+  for (auto& e : h->graphs)
+    if (e.key == k) { e.used = ++h->graph_clock; return &e; }
+  return nullptr;
+}
+
+// the fork point a TIMED graph of this geometry was built with (any relaxation / bound / kind: the point depends on the
+// launch durations, which these do not change), or null
+const char* tuned_fork_for(const sga_handle* h, int B, int H, int W, bool* found) {
+  *found = false;
+  for (const auto& e : h->graphs)
+    if (e.tuned && e.key.B == B && e.key.H == H && e.key.W == W) { *found = true; return e.fork_name; }
+  return nullptr;
+}
+
+sga_handle::GraphEntry* insert_graph(sga_handle* h, const sga_handle::GraphKey& k, hipGraphExec_t ex, bool tuned, const char* fork_name,
+                                     bool stamp_in_graph, hipStream_t st) {
+  if (h->graphs.size() >= kMaxGraphs) {      // the least recently used entry makes room (retired, or destroyed behind a synchronisation)
+    size_t lru = 0;
+    for (size_t i = 1; i < h->graphs.size(); ++i) if (h->graphs[i].used < h->graphs[lru].used) lru = i;
+    (void)hipStreamSynchronize(st);
+    drop_graph(h, h->graphs[lru].exec, st);
+    h->graphs.erase(h->graphs.begin() + (long)lru);
+    ++h->n_graph_evictions;
+  }
+  h->graphs.push_back(sga_handle::GraphEntry{k, ex, tuned, fork_name, stamp_in_graph, ++h->graph_clock});
+  return &h->graphs.back();
+}
+
+void erase_graph(sga_handle* h, sga_handle::GraphEntry* e, hipStream_t st) {
+  (void)hipStreamSynchronize(st);      // replays of it may still be queued
+  drop_graph(h, e->exec, st);
+  h->graphs.erase(h->graphs.begin() + (e - h->graphs.data()));
+}
+
 // The fork point of the hyper branch, chosen by time: captures one step graph per candidate (`capture` records
 // one iteration under the current h->fork_name), replays each a few times -- on the caller's live state: the replays are
 // iterations of the run and are counted in *done -- and returns the fastest; the others are retired (sga_handle::retired_graphs).
@@ -1413,10 +1467,10 @@ int timed_fork_choice(sga_handle* h, hipStream_t st, int B, int H, int W, Cap&& 
 }
 
 void free_all(sga_handle* h) {
-  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  for (auto& e : h->graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
+  h->graphs.clear();
   for (hipGraphExec_t gx : h->retired_graphs) (void)hipGraphExecDestroy(gx);
   if (h->graph_main) (void)hipGraphExecDestroy(h->graph_main);
-  for (int k = 0; k < 2; ++k) if (h->bb_graph[k]) (void)hipGraphExecDestroy(h->bb_graph[k]);
   for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   if (h->ev_fork2_cap) (void)hipEventDestroy(h->ev_fork2_cap);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -2045,11 +2099,13 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
   }
 
   bool graphed = false;
+  hipGraphExec_t step_graph = nullptr;
   int tuned_done = 0;              // iterations of this call already run by the fork-point candidates
   if (h->use_graph && !h->profiling) {
     auto capture = [&]() -> hipGraphExec_t {
       hipGraphExec_t ex = nullptr;
       hipGraph_t graph = nullptr;
+      ++h->n_captures;
       if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         const int rc = enqueue_step(st);
         const hipError_t ec = hipStreamEndCapture(st, &graph);
@@ -2067,31 +2123,35 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
     // the run's own iterations: 8 replays of each candidate graph, which count -- and keeps the fastest graph
     // (DESIGN.md 3.7).  SGA_FORK_AT=<n> pins the point instead.
     const bool tune = h->fork_auto && fb && h->overlap && (!h->x3 || h->x3_fork) && !h->gprof && n >= 100;
-    const bool stale = !h->graph_exec || h->graph_B != B || h->graph_H != H || h->graph_W != W || h->graph_relax != h->relax;
-    if (stale || (tune && !h->graph_tuned)) {
-      if (h->graph_exec) {
-        // replays of the old graph may still be queued (a short run followed at once by a long one): let them finish
-        // before the executable graph is destroyed
-        HIPCHK(h, hipStreamSynchronize(st));
-        drop_graph(h, h->graph_exec, st);
-      }
-      h->graph_tuned = false;
-      if (!tune) {
-        if (h->fork_auto) h->fork_name = (h->tuned_B == B && h->tuned_H == H && h->tuned_W == W) ? h->tuned_name : nullptr;
-        h->graph_exec = capture();
-        h->graph_tuned = h->fork_auto && h->tuned_B == B && h->tuned_H == H && h->tuned_W == W;
-      } else {
-        SGACHK(timed_fork_choice(h, st, B, H, W, capture, &h->graph_exec, &tuned_done));
-        h->graph_tuned = h->graph_exec != nullptr;
-        if (!h->graph_exec) { h->fork_name = nullptr; h->graph_exec = capture(); }
-      }
-      if (h->graph_exec) { h->graph_B = B; h->graph_H = H; h->graph_W = W; h->graph_relax = h->relax; }
+    const sga_handle::GraphKey key{0, B, H, W, h->relax, h->scale_bound, h->gprof ? 1 : 0};
+    sga_handle::GraphEntry* e = find_graph(h, key);
+    if (e && tune && !e->tuned) {      // built untimed by a short call: this call has the iterations to time the candidates
+      erase_graph(h, e, st);
+      e = nullptr;
     }
-    graphed = h->graph_exec != nullptr;
+    if (!e) {
+      hipGraphExec_t ex = nullptr;
+      bool tuned = false;
+      if (!tune) {
+        if (h->fork_auto) h->fork_name = tuned_fork_for(h, B, H, W, &tuned);
+        ex = capture();
+      } else {
+        SGACHK(timed_fork_choice(h, st, B, H, W, capture, &ex, &tuned_done));
+        tuned = ex != nullptr;
+        if (!ex) { h->fork_name = nullptr; ex = capture(); }
+      }
+      if (ex) e = insert_graph(h, key, ex, tuned, h->fork_name, h->gprof_in_graph, st);
+    } else {
+      if (h->fork_auto) h->fork_name = e->fork_name;
+      if (h->gprof) h->gprof_in_graph = e->stamp_in_graph;
+    }
+    h->graph_tuned = e && e->tuned;
+    step_graph = e ? e->exec : nullptr;
+    graphed = step_graph != nullptr;
   }
   for (int k = tuned_done; k < n; ++k) {
     h->dbg_it = h->run_it + k;
-    if (graphed) HIPCHK(h, hipGraphLaunch(h->graph_exec, st));
+    if (graphed) HIPCHK(h, hipGraphLaunch(step_graph, st));
     else SGACHK(enqueue_step(st));
     if (graphed && h->gprof && h->gprof_in_graph) {      // measurement: the stamped kernel's span in this replay
       unsigned long long t[2] = {0, 0};
@@ -2185,8 +2245,9 @@ int sga_quantize_centered(sga_handle* h, const float* y, const float* z, int B, 
 int sga_base_compress_bound(sga_handle* h, const float* x, int B, int H, int W, const float* medians, float scale_bound,
                             float* y_hat, float* z_hat, float* metrics, void* stream) {
   if (!h || !(scale_bound >= 0.f) || !(scale_bound < 1e30f)) return SGA_ERR_BAD_ARG;
-  // the call launches eagerly (no captured graph is involved), so the bound is an argument of THIS call's k_gaussian launch
-  // only: nothing is synchronised, no cached step graph is dropped
+  // the call launches eagerly (no captured graph is involved) and the bound crosses to the device BY VALUE as an argument of
+  // this call's k_gaussian launch: the host field is read while the launches are enqueued and restored before returning, so
+  // nothing is synchronised, no cached step graph is dropped and no launch in flight sees the temporary value
   const float keep = h->scale_bound;
   h->scale_bound = scale_bound;
   const int rc = sga_base_compress(h, x, B, H, W, medians, y_hat, z_hat, metrics, stream);
@@ -2203,13 +2264,17 @@ int sga_base_compress(sga_handle* h, const float* x, int B, int H, int W, const 
   const int C = h->C;
   const int64_t nz = (int64_t)B * g.zh * g.zw * C;
   SGACHK(ensure_borders(h, g, st));
-  SGACHK(encode_impl(h, g, x, h->y.p, h->z.p, st));
-  HIPCHK(h, launch_round_median(h->z.p, medians, nz, C, z_hat, st));           // mbt2018.py:69
+  // y, z go to scratch -- two gradient buffers of the same sizes that every SGA iteration rewrites before it reads them --
+  // NOT to h->y / h->z: those are the live latents of a run opened by sga_run_begin, which a one-shot encode between two
+  // sga_run_steps calls must leave alone (tests/test_gpu_configs.py::test_base_compress_inside_an_open_run)
+  float* const ybuf = h->g_yt_dist.p; float* const zbuf = h->g_zt_eb.p;
+  SGACHK(encode_impl(h, g, x, ybuf, zbuf, st));
+  HIPCHK(h, launch_round_median(zbuf, medians, nz, C, z_hat, st));             // mbt2018.py:69
   // mu = h_s(z_hat)[..., :C] (mbt2018.py:70-76), y_hat = round(y - mu) + mu (mbt2018.py:80)
   SGACHK(deconv_fwd(h, h->hs_f[0], h->hs_bias[0], z_hat, B, g.zh, g.zw, h->hs0.p, EPI_BIAS_RELU, st));
   SGACHK(deconv_fwd(h, h->hs_f[1], h->hs_bias[1], h->hs0.p, B, 2 * g.zh, 2 * g.zw, h->hs1.p, EPI_BIAS_RELU, st));
   SGACHK(conv3(h, h->hs_f[2], h->hs_bias[2], h->hs1.p, h->C15, B, g.hsh, g.hsw, h->ms.p, true, EPI_BIAS, nullptr, st));
-  HIPCHK(h, launch_round_centered(h->y.p, h->ms.p, B, g.yh, g.yw, g.hsh, g.hsw, C, y_hat, st));
+  HIPCHK(h, launch_round_centered(ybuf, h->ms.p, B, g.yh, g.yw, g.hsh, g.hsw, C, y_hat, st));
   if (metrics) SGACHK(eval_impl(h, g, x, y_hat, z_hat, metrics, nullptr, st));
   return SGA_OK;
 }
@@ -2365,11 +2430,7 @@ int sga_op_rate_terms(sga_handle* h, const float* y_tilde, const float* z_tilde,
 // The bound is a launch argument of k_gaussian, i.e. part of every captured step graph: drop them.
 int sga_set_scale_bound(sga_handle* h, float scale_bound) {
   if (!h || !(scale_bound >= 0.f) || !(scale_bound < 1e30f)) return SGA_ERR_BAD_ARG;
-  if (scale_bound == h->scale_bound) return SGA_OK;
-  HIPCHK(h, hipDeviceSynchronize());
-  drop_graph(h, h->graph_exec);
-  for (int k = 0; k < 2; ++k) drop_graph(h, h->bb_graph[k]);
-  h->bb_graph_tuned = false;
+  // the bound is part of the graph cache's key: the graphs captured under the other value stay cached, nothing is synchronised
   h->scale_bound = scale_bound;
   return SGA_OK;
 }
@@ -2403,7 +2464,8 @@ int sga_profile_graph_begin(sga_handle* h, const char* kernel_name) {
     const unsigned long long reset[2] = {~0ull, 0ull};
     HIPCHK(h, hipMemcpy(h->gstamp, reset, sizeof(reset), hipMemcpyHostToDevice));
   }
-  drop_graph(h, h->graph_exec);      // re-capture with the pair
+  for (size_t i = h->graphs.size(); i-- > 0;)      // an older stamped graph may carry another kernel's stamp: capture afresh
+    if (h->graphs[i].key.stamped) { drop_graph(h, h->graphs[i].exec); h->graphs.erase(h->graphs.begin() + (long)i); }
   strncpy(h->gprof_name, kernel_name, sizeof(h->gprof_name) - 1);
   h->gprof_name[sizeof(h->gprof_name) - 1] = 0;
   h->gprof = true; h->gprof_in_graph = false;
@@ -2419,6 +2481,17 @@ int sga_get_fork_point(const sga_handle* h, char* name, int name_len) {
   return SGA_OK;
 }
 
+int sga_debug_counter(const sga_handle* h, int which, long long* value) {
+  if (!h || !value) return SGA_ERR_BAD_ARG;
+  switch (which) {
+    case SGA_COUNTER_GRAPH_CAPTURES: *value = h->n_captures; return SGA_OK;
+    case SGA_COUNTER_GRAPHS_CACHED: *value = (long long)h->graphs.size(); return SGA_OK;
+    case SGA_COUNTER_GRAPH_EVICTIONS: *value = h->n_graph_evictions; return SGA_OK;
+    case SGA_COUNTER_GRAPHS_RETIRED: *value = (long long)h->retired_graphs.size(); return SGA_OK;
+  }
+  return SGA_ERR_BAD_ARG;
+}
+
 int sga_profile_graph_end(sga_handle* h, sga_kernel_stat* out) {
   if (!h || !out) return SGA_ERR_BAD_ARG;
   HIPCHK(h, hipDeviceSynchronize());
@@ -2426,7 +2499,8 @@ int sga_profile_graph_end(sga_handle* h, sga_kernel_stat* out) {
   strncpy(out->name, h->gprof_name, sizeof(out->name) - 1);
   out->launches = h->gprof_n; out->ms_total = h->gprof_ms; out->flops_total = h->gprof_flops;
   h->gprof = false; h->gprof_in_graph = false;
-  drop_graph(h, h->graph_exec);      // production graph next time
+  for (size_t i = h->graphs.size(); i-- > 0;)      // the production graphs are still cached under their own keys
+    if (h->graphs[i].key.stamped) { drop_graph(h, h->graphs[i].exec); h->graphs.erase(h->graphs.begin() + (long)i); }
   return SGA_OK;
 }
 
@@ -2523,17 +2597,13 @@ int bb_eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_ha
 template <typename F>
 int bb_iterations(sga_handle* h, int stage, const Geom& g, int n, hipStream_t st, F&& enqueue) {
   bool graphed = false;
+  hipGraphExec_t bb_graph = nullptr;
   int done = 0;                    // iterations already run by the fork-point candidates
   if (h->use_graph && !h->profiling && n > 0) {
-    if (h->bb_graph_B != g.B || h->bb_graph_H != g.H || h->bb_graph_W != g.W) {
-      HIPCHK(h, hipStreamSynchronize(st));
-      for (int k = 0; k < 2; ++k) drop_graph(h, h->bb_graph[k], st);
-      h->bb_graph_B = g.B; h->bb_graph_H = g.H; h->bb_graph_W = g.W;
-      h->bb_graph_tuned = false;
-    }
     auto capture = [&]() -> hipGraphExec_t {
       hipGraphExec_t ex = nullptr;
       hipGraph_t graph = nullptr;
+      ++h->n_captures;
       if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         const int rc = enqueue();
         const hipError_t ec = hipStreamEndCapture(st, &graph);
@@ -2546,24 +2616,30 @@ int bb_iterations(sga_handle* h, int stage, const Geom& g, int n, hipStream_t st
     };
     // stage 1 (the full step, bb_sga.py:203-236) forks the hyper branch like the plain SGA step: its fork point is timed the
     // same way (stage 2 is the hyper branch alone: nothing to fork)
-    const bool tune = stage == 0 && h->fork_auto && h->overlap && (!h->x3 || h->x3_fork) && n >= 100 && !h->bb_graph_tuned;
-    if (tune && h->bb_graph[0]) {
-      HIPCHK(h, hipStreamSynchronize(st));
-      drop_graph(h, h->bb_graph[0], st);
-    }
-    if (!h->bb_graph[stage]) {
+    const sga_handle::GraphKey key{1 + stage, g.B, g.H, g.W, 0, h->scale_bound, 0};
+    sga_handle::GraphEntry* e = find_graph(h, key);
+    const bool tune = stage == 0 && h->fork_auto && h->overlap && (!h->x3 || h->x3_fork) && n >= 100 && !(e && e->tuned);
+    if (e && tune) { erase_graph(h, e, st); e = nullptr; }
+    if (!e) {
+      hipGraphExec_t ex = nullptr;
+      bool tuned = false;
       if (tune) {
-        SGACHK(timed_fork_choice(h, st, g.B, g.H, g.W, capture, &h->bb_graph[0], &done));
-        h->bb_graph_tuned = h->bb_graph[0] != nullptr;
+        SGACHK(timed_fork_choice(h, st, g.B, g.H, g.W, capture, &ex, &done));
+        tuned = ex != nullptr;
       } else if (stage == 0 && h->fork_auto) {
-        h->fork_name = (h->tuned_B == g.B && h->tuned_H == g.H && h->tuned_W == g.W) ? h->tuned_name : nullptr;
+        h->fork_name = tuned_fork_for(h, g.B, g.H, g.W, &tuned);
       }
-      if (!h->bb_graph[stage]) h->bb_graph[stage] = capture();
+      if (!ex) ex = capture();
+      if (ex) e = insert_graph(h, key, ex, tuned, stage == 0 ? h->fork_name : nullptr, false, st);
+    } else if (stage == 0 && h->fork_auto) {
+      h->fork_name = e->fork_name;
     }
-    graphed = h->bb_graph[stage] != nullptr;
+    if (stage == 0) h->bb_graph_tuned = e && e->tuned;
+    bb_graph = e ? e->exec : nullptr;
+    graphed = bb_graph != nullptr;
   }
   for (int it = done; it < n; ++it) {
-    if (graphed) HIPCHK(h, hipGraphLaunch(h->bb_graph[stage], st));
+    if (graphed) HIPCHK(h, hipGraphLaunch(bb_graph, st));
     else SGACHK(enqueue());
   }
   return SGA_OK;

@@ -188,7 +188,8 @@ def run_early_stop(codec, x, lmbda, *, method, its=2000, lr, seed=0, loss_scale=
     return y_hat, z_hat, codec.evaluate(x, y_hat, z_hat), done
 
 
-def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, loss_scale, log_itv=100, log=print, after=None):
+def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, loss_scale, log_itv=100, log=print, after=None,
+                latents=None):
     """sga.py:210-238 with --verbose: at every log point also feed the ROUNDED latents straight into
     the graph (sga.py:219-225) and print both objectives.  The run pauses at the log points
     (sga_run_steps); the rounded latents are evaluated with the relaxation switched off."""
@@ -215,6 +216,8 @@ def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, los
             % (it, T, t[0], t[1], t[2], t[3], r["rd_loss"], r["train_bpp"], float(r["psnr"].mean())))
     if y is None:
         y, z = codec.run_latents()
+    if latents is not None:                                                 # the rounded latents, for sga.py:281-291
+        latents.append(torch.round(y))
     return codec.evaluate(x, torch.round(y), torch.round(z))                # sga.py:240-245
 
 
@@ -274,9 +277,13 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
                     codec.set_relaxation("sga", "exp0")
             elif verbose:
                 after = [] if opt_record is not None else None
+                lat = [] if recon is not None else None
                 met = run_verbose(codec, X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate, t0=t0,
-                                  T_ub=T_ub, seed=sd, loss_scale=loss_scale, log_itv=log_itv, log=log, after=after)
+                                  T_ub=T_ub, seed=sd, loss_scale=loss_scale, log_itv=log_itv, log=log, after=after, latents=lat)
                 tr = codec.run_latents(trace=True)[2] if want_trace else None
+                if recon is not None:                                       # sga.py:281-291 writes it regardless of --verbose
+                    for k, xh in zip(idx, codec.reconstruct(lat[0], H, W).cpu().numpy()):
+                        recon.append((k, xh))
             else:
                 y_hat_l, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate,
                                                 t0=t0, T_ub=T_ub, seed=sd, loss_scale=loss_scale,
@@ -411,7 +418,8 @@ def compress(args, weights=None):
     opt_record = {} if getattr(args, "save_opt_record", False) else None
     recon = [] if getattr(args, "save_reconstruction", False) else None
     if recon is not None:
-        assert N == 1 and method == "sga", "--save_reconstruction: one image, --method sga (sga.py:282)"
+        if not (N == 1 and method == "sga"):      # (not an assert: it must survive python -O)
+            raise ValueError("--save_reconstruction: one image, --method sga (sga.py:282)")
     res = run_dataset(codec, X, args.lmbda, its=args.sga_its, annealing_rate=args.annealing_rate,
                       t0=args.t0, seed=args.seed, rank=rank, world=world, dist=dist,
                       verbose=args.verbose, method=method, base_scale_bound=sb,
@@ -439,7 +447,8 @@ def compress(args, weights=None):
 
 def main(argv=None):
     args = parse_args(sys.argv[1:] if argv is None else argv)
-    assert args.command == "compress", "Only compression is supported."     # sga.py:303
+    if args.command != "compress":                                          # sga.py:303
+        raise ValueError("Only compression is supported.")
     if args.num_filters <= 0:
         raise SystemExit("--num_filters is required")
     return compress(args)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGA_ABI_VERSION 3
+#define SGA_ABI_VERSION 4
 
 typedef enum sga_status {
   SGA_OK = 0,
@@ -116,7 +116,8 @@ int sga_last_error(const sga_handle* h, char* msg, int msg_len);
 /* latent geometry for an HxW image: y is [h,w,C], z is [hz,wz,C] (sga.py:77-78) */
 int sga_latent_shape(const sga_handle* h, int H, int W, int* yh, int* yw, int* zh, int* zw);
 /* change sga_config.scale_bound of a live handle (e.g. SGA_SCALE_BOUND_BUILT around sga_base_compress on a handle
- * that otherwise runs SGA).  Synchronises the device and drops the cached step graphs. */
+ * that otherwise runs SGA).  Host-side only since ABI 4: the bound is part of the key of the handle's graph cache, so the
+ * graphs captured under the other value stay cached and are selected again when it comes back. */
 int sga_set_scale_bound(sga_handle* h, float scale_bound);
 
 /* ---- sharding: which images of the reference batch does this handle hold? ----
@@ -196,8 +197,10 @@ int sga_eval(sga_handle* h, const float* x, int B, int H, int W,
 int sga_base_compress(sga_handle* h, const float* x, int B, int H, int W, const float* medians,
                       float* y_hat, float* z_hat, float* metrics, void* stream);
 /* The same with the sigma bound as an argument of THIS call (SGA_SCALE_BOUND_BUILT mirrors mbt2018.py:80): the handle's
- * bound, its cached step graphs and work in flight are left alone (the call launches eagerly).  What a handle that
- * otherwise runs SGA should use instead of sga_set_scale_bound around sga_base_compress. */
+ * bound and its cached step graphs are left alone (the call launches eagerly; the bound reaches the device by value).  Both
+ * forms encode into scratch, not into the latents of a run opened by sga_run_begin, so they may be called between two
+ * sga_run_steps calls; like every entry point they use the handle's activation workspace and must be issued on the run's
+ * stream.  What a handle that otherwise runs SGA should use instead of sga_set_scale_bound around sga_base_compress. */
 int sga_base_compress_bound(sga_handle* h, const float* x, int B, int H, int W, const float* medians, float scale_bound,
                             float* y_hat, float* z_hat, float* metrics, void* stream);
 
@@ -348,6 +351,17 @@ int sga_profile_graph_end(sga_handle* h, sga_kernel_stat* out);
  * chosen by time, once per geometry, by the first sga_run_steps call with >= 100 iterations (it changes no
  * bit of any result); "untimed" while no such call has been made.  Reporting only. */
 int sga_get_fork_point(const sga_handle* h, char* name, int name_len);
+
+/* Counters of the handle's cache of executable step graphs (ABI 4; reporting / tests only).  One captured iteration is kept
+ * per (kind, B, H, W, relaxation, sigma bound): a geometry that comes back -- a ragged last batch, a service alternating two
+ * sizes -- is SELECTED, never re-captured or re-timed; entries live until sga_destroy. */
+typedef enum sga_counter {
+  SGA_COUNTER_GRAPH_CAPTURES = 0,   /* stream captures + instantiations so far (3 per timed geometry, 1 per untimed one) */
+  SGA_COUNTER_GRAPHS_CACHED = 1,    /* live entries */
+  SGA_COUNTER_GRAPH_EVICTIONS = 2,  /* entries retired because the cache was full (16) */
+  SGA_COUNTER_GRAPHS_RETIRED = 3    /* dropped executable graphs kept until sga_destroy (losing fork-point candidates, evictions) */
+} sga_counter;
+int sga_debug_counter(const sga_handle* h, int which, long long* value);
 
 #ifdef __cplusplus
 }

@@ -157,13 +157,16 @@ def _acceptance(gpu_out_dir, golden, precision, tag):
     assert abs(rep["mean_d_psnr"]) <= TOL_PSNR, rep
     if bb:
         assert abs(rep["mean_d_bpp_back"]) <= TOL_BPP, rep
-    # per image (mean over the seeds): no systematic offset of any image beyond the tolerance (or 3.5 standard errors
-    # of that image's mean when it has fewer than 16 seeds)
-    # (a per-image mean over k seeds carries a standard error of std / sqrt(k): where that is not small against the
-    # tolerance -- few seeds, or the trained-like sets whose single runs scatter by 0.04 dB -- the bound is 3.5 standard errors)
+    # per image (mean over the seeds): no systematic offset of any image beyond the tolerance.  HARD bounds (1e-3 bpp, 0.01 dB)
+    # for every set whose single runs scatter by less than the tolerance (all sets of rounds 1-3 with >= 16 seeds).  Only where
+    # a per-image mean over k seeds carries a standard error that is not small against the tolerance -- fewer than 16 seeds, or
+    # the trained-like sets (config key `weights`: fitted models, single runs scatter by 0.04 dB) -- the bound is 3.5 standard
+    # errors of that image's mean (the allowance is no longer applied to the synthetic-weight sets)
     k = d_bpp.shape[0]
-    img_tol = np.maximum(TOL_BPP, 3.5 * d_bpp.std(0, ddof=1) / np.sqrt(k))
-    img_tol_p = np.maximum(TOL_PSNR, 3.5 * d_psnr.std(0, ddof=1) / np.sqrt(k))
+    noisy = k < 16 or bool(cfg.get("weights"))
+    rep["per_image_criterion"] = "3.5 standard errors (noisy set)" if noisy else "hard 1e-3 bpp / 0.01 dB"
+    img_tol = np.maximum(TOL_BPP, 3.5 * d_bpp.std(0, ddof=1) / np.sqrt(k)) if noisy else np.full(d_bpp.shape[1], TOL_BPP)
+    img_tol_p = np.maximum(TOL_PSNR, 3.5 * d_psnr.std(0, ddof=1) / np.sqrt(k)) if noisy else np.full(d_psnr.shape[1], TOL_PSNR)
     rep["per_image_tol_bpp"], rep["per_image_tol_psnr"] = img_tol.tolist(), img_tol_p.tolist()
     assert (np.abs(d_bpp.mean(0)) <= img_tol).all(), rep
     assert (np.abs(d_psnr.mean(0)) <= img_tol_p).all(), rep
@@ -216,7 +219,7 @@ def test_trace_at_the_benchmarked_geometry(gpu_out_dir):
     rel = np.abs(got / want - 1)
     rep = dict(its=int(cfg["its"]), max_rel_first_100=rel[:100].max(0).tolist(), max_rel_all=rel.max(0).tolist(),
                rd_loss_first=float(want[0, 0]), rd_loss_last=float(want[-1, 0]), rd_loss_last_hip=float(got[-1, 0]),
-               frac_nonzero_y_hat_oracle=run.get("frac_nonzero_y_hat"), frac_nonzero_y_hat_hip=float((y_hat != 0).float().mean()))
+               frac_nonzero_y_hat_oracle=run.get("frac_nonzero_y_hat", (1.0 - run["frac_zero_y_hat"]) if "frac_zero_y_hat" in run else None), frac_nonzero_y_hat_hip=float((y_hat != 0).float().mean()))
     with open(os.path.join(gpu_out_dir, "acceptance_trace_cfg2.json"), "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps(rep))
@@ -265,7 +268,7 @@ def test_trace_2000_at_the_production_schedule(gpu_out_dir):
                rd_loss_first=float(want[0, 0]), rd_loss_last=float(want[-1, 0]), rd_loss_last_hip=float(got[-1, 0]),
                end_d_bpp_mean=float(m["est_bpp"].mean() - np.mean(run["est_bpp"])),
                end_d_psnr_mean=float(m["psnr"].mean() - np.mean(run["psnr"])),
-               frac_nonzero_y_hat_oracle=run.get("frac_nonzero_y_hat"), frac_nonzero_y_hat_hip=float((y_hat != 0).float().mean()))
+               frac_nonzero_y_hat_oracle=run.get("frac_nonzero_y_hat", (1.0 - run["frac_zero_y_hat"]) if "frac_zero_y_hat" in run else None), frac_nonzero_y_hat_hip=float((y_hat != 0).float().mean()))
     with open(os.path.join(gpu_out_dir, "acceptance_trace2000_cfg2.json"), "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps(rep))

@@ -354,6 +354,75 @@ def test_base_compress_between_runs_leaves_the_step_graph_alone():
     codec.close(); built.close()
 
 
+def test_graph_cache_selects_instead_of_recapturing():
+    """the handle keeps one executable step graph per (geometry, relaxation, sigma bound) with its timed fork
+    point.  Alternating three geometries (a ragged last batch, a service with two image sizes), toggling the sigma bound and
+    the relaxation: after the first pass NOTHING is captured again, nothing is retired, and every run is bit-identical to
+    the first run of its kind."""
+    from sga_amd.codec import SGACodec
+    C = 64
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    codec = SGACodec(w, C, 3, 80, 96)
+    geos = [(3, 80, 96), (2, 80, 96), (1, 64, 48)]
+    xs = [np.random.RandomState(10 + i).rand(b, hh, ww, 3).astype(np.float32) for i, (b, hh, ww) in enumerate(geos)]
+    first = [codec.run(x, 0.01, its=110, seed=3) for x in xs]          # >= 100 iterations: three candidates timed per geometry
+    assert codec.counter("captures") == 9 and codec.counter("cached") == 3
+    retired = codec.counter("retired")                                 # the losing candidates (kept until sga_destroy)
+    assert retired == 6
+    for rnd in range(20):
+        for x, ref in zip(xs, first):
+            out = codec.run(x, 0.01, its=110 if rnd == 0 else 12, seed=3)
+            if rnd == 0:
+                assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    assert codec.counter("captures") == 9 and codec.counter("cached") == 3 and codec.counter("retired") == retired
+    # the sigma bound and the relaxation are part of the key: a new value captures ONE more graph (it inherits the
+    # geometry's timed fork point), coming back to the old value captures nothing
+    fp = codec.fork_point()
+    codec.set_scale_bound(0.11)
+    b1 = codec.run(xs[2], 0.01, its=30, seed=3)
+    assert codec.counter("captures") == 10 and codec.fork_point() == fp
+    codec.set_scale_bound(0.0)
+    again = codec.run(xs[2], 0.01, its=110, seed=3)
+    assert codec.counter("captures") == 10
+    assert torch.equal(again[0], first[2][0]) and torch.equal(again[1], first[2][1])
+    codec.set_scale_bound(0.11)
+    b2 = codec.run(xs[2], 0.01, its=30, seed=3)
+    assert codec.counter("captures") == 10 and torch.equal(b1[0], b2[0])
+    codec.set_scale_bound(0.0)
+    codec.set_relaxation("unoise", "exp0")
+    u1 = codec.run(xs[1], 0.01, its=20, seed=3)
+    codec.set_relaxation("sga", "exp0")
+    s1 = codec.run(xs[1], 0.01, its=110, seed=3)
+    codec.set_relaxation("unoise", "exp0")
+    u2 = codec.run(xs[1], 0.01, its=20, seed=3)
+    codec.set_relaxation("sga", "exp0")
+    assert codec.counter("captures") == 11 and codec.counter("evictions") == 0
+    assert torch.equal(u1[0], u2[0]) and torch.equal(s1[0], first[1][0])
+    codec.close()
+
+
+def test_base_compress_inside_an_open_run():
+    """the one-shot encode (mbt2018.py:64-81) used h->y / h->z -- the live latents of a run opened by sga_run_begin --
+    as temporaries.  It encodes into scratch now: called between two sga_run_steps calls it returns what it returns on an idle
+    handle and the interrupted run ends bit-identically to the uninterrupted one."""
+    from sga_amd.codec import SGACodec
+    C, B, H, W = 64, 2, 64, 64
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    x = np.random.RandomState(4).rand(B, H, W, 3).astype(np.float32)
+    x2 = np.random.RandomState(5).rand(B, H, W, 3).astype(np.float32)
+    codec = SGACodec(w, C, B, H, W)
+    ref = codec.run(x, 0.01, its=60, seed=5)
+    idle = codec.base_compress(x2)
+    codec.run_begin(x, 0.01, its=60, seed=5)
+    codec.run_steps(25)
+    mid = codec.base_compress(x2)                          # another image, in the middle of the run
+    codec.run_steps(35)
+    y, z = codec.run_latents()
+    assert torch.equal(torch.round(y), ref[0]) and torch.equal(torch.round(z), ref[1])
+    assert torch.equal(mid[0], idle[0]) and torch.equal(mid[1], idle[1])
+    codec.close()
+
+
 def test_bits_back_step_at_kodak_size_trained_like_weights(gpu_out_dir):
     """cfg 5 at Kodak size WITHOUT touching the posterior: the bits-back model fitted by
     tests/tools/fit_weights.py (C = 64; log-variances 0.5 .. 3.1) needs no clipping of (z_mean, z_logvar) and no scaled

@@ -307,9 +307,12 @@ def test_persistent_igdn_bwd_equals_the_tile_kernel(C, B, H, W, sched, monkeypat
     tile = SGACodec(w, C, B, H, W, lab=True)
     x = np.random.RandomState(C + H).rand(B, H, W, 3).astype(np.float32)
     y, z = tile.encode(x)
-    ws.profile_begin(); ra = ws.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5); names = [k["name"] for k in ws.profile_end()]
-    rb = tile.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    # (the profiled call only shows which kernel ran: profiling is single-stream, and at large shapes the hyper branch's split-K
+    #  slab count is capped by the buffer of the stream it runs on -- another summation order than the two-stream step)
+    ws.profile_begin(); ws.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5); names = [k["name"] for k in ws.profile_end()]
     assert any(n.replace(" ", "").startswith("igdn_bwd_ws_kernel<%d>" % (C // 32)) for n in names), names
+    ra = ws.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
+    rb = tile.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
     assert float(ra["gy"].abs().max()) > 0
     assert torch.equal(ra["gy"], rb["gy"]) and torch.equal(ra["gz"], rb["gz"]) and ra["rd_loss"] == rb["rd_loss"]
     # repeated launches (the shared tile counter must be back at zero) and the graph replay

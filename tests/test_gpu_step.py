@@ -489,6 +489,14 @@ def test_driver_aux_outputs_and_finite_check(tmp_path):
     driver.main(["--verbose"] + base[:4] + [str(out2)] + base[5:] + [runname, str(inp)])
     rec2 = dict(np.load(out2 / opt))
     assert rec2["rd_loss_after_rounding"].shape == (4,) and np.allclose(rec2["rd_loss"], rec["rd_loss"], rtol=1e-6)
+    # ... and still writes the reconstruction (sga.py:281-291 does so regardless of --verbose): the same image
+    recon2 = [f for f in sorted(os.listdir(out2)) if f.startswith("recon-") and f.endswith(".png")]
+    assert len(recon2) == 1, sorted(os.listdir(out2))
+    assert np.array_equal(np.asarray(Image.open(out2 / recon2[0])), xr)
+    with pytest.raises(ValueError, match="save_reconstruction"):      # (a ValueError, not an assert: survives python -O)
+        two = tmp_path / "two.npy"
+        np.save(two, np.stack([img, img]))
+        driver.main(base + [runname, str(two)])
     # a run that goes non-finite: a NaN pixel -> NaN objective from iteration 0; the check names the iteration
     bad = np.stack([img.astype(np.float32)])
     npy = tmp_path / "bad.npy"

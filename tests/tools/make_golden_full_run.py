@@ -66,6 +66,13 @@ CFGS = {
     # never builds the conditional layer either), both stages
     "bb_fitted": dict(C=64, B=2, H=64, W=64, its=2000, r_its=2000, lmbda=0.01, x_seed=23, weight_seed=0, bb=True, scale_bound=0.0,
                       weights="fitted_c64bb", inputs="lowpass", seeds=list(range(32))),
+    # The same at the NORTH STAR'S WIDTH (round 5): C = 192 fitted by `FIT_C=192 tests/tools/fit_weights.py`
+    # (tests/golden/fitted_weights_c192.npz: 0.39 bpp / 33.5 dB one-shot, 87 % of y_hat at 0, 78 % of the predicted scales below
+    # 0.11), 2 x 128^2 low-pass images, both sigma-bound modes; ~5 min per seed on one core
+    "fitted_c192": dict(C=192, B=2, H=128, W=128, its=2000, lmbda=0.01, x_seed=25, weight_seed=0, scale_bound=0.0,
+                        weights="fitted_c192", inputs="lowpass", seeds=list(range(16))),
+    "fitted_c192_b011": dict(C=192, B=2, H=128, W=128, its=2000, lmbda=0.01, x_seed=25, weight_seed=0, scale_bound=0.11,
+                             weights="fitted_c192", inputs="lowpass", seeds=list(range(16))),
     # CONTROL for the statistical criterion: the small set's inputs and Philox seeds through the float64 oracle.  The
     # float32-vs-float64 ORACLE difference is what "a different rounding of the same arithmetic" does to a 2000-step run;
     # tests/test_oracle.py asserts it has the spread the GPU acceptance test tolerates
