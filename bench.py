@@ -36,6 +36,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md; AMD's 5 PF headline includes 2:1 sparsity)
+# what a register-only loop of v_mfma_f32_32x32x16_bf16 sustains on RANDOM operands at the package's power limit (one / two waves
+# per SIMD; profiles/r04_mfma_sustained_bf16_f32.txt) -- the practical ceiling of the bf16 modes, beside the nominal peak
+BF16_MFMA_SUSTAINED_RANDOM_TFLOPS = (1330.0, 1656.0)
+PLANE_PRODUCTS_PER_MAC = {"bf16x3": 6, "bf16x2": 3}   # bf16 MFMA products issued per algorithmic multiply-add
 
 
 def gflop_per_image_step(H, W, C):
@@ -268,8 +273,8 @@ def main():
     # ---- secondary measurements: the other precision modes, same workload (one warm-up + up to 3 timed steps each) -----------
     NOTES = {
         "bf16x3": "same algorithmic FLOPs on the bf16 matrix pipe: every f32 operand split exactly into 3 bf16 planes, 6 "
-                  "plane products per MAC, f32 accumulate (f32-grade accuracy; DESIGN.md 3.6); a fraction of the fp32-MFMA "
-                  "peak above 1 is possible in this mode and is not a claim about the f32 roofline",
+                  "plane products per MAC, f32 accumulate (f32-grade accuracy; DESIGN.md 3.6); its roofline is the bf16 pipe's "
+                  "(`roofline`: issued plane-product FLOPs against 2.5 PF dense), not the fp32 one",
         "bf16x2": "NOT f32-grade: convolution operands rounded to 16 mantissa bits (2 bf16 planes, 3 plane products per MAC, f32 "
                   "accumulate; TF32 keeps 11 bits); single layers agree with float64 to 1e-5, one complete step at this shape to 3.5e-4 (gy) / "
                   "3.8e-3 (gz) of the gradient maxima (f32 path: 1e-5 / 2e-5), the 2000-step acceptance sets end within the north-star "
@@ -286,10 +291,10 @@ def main():
             met2 = one_step(100 + i, codec2)
         torch.cuda.synchronize(device)
         el2 = time.perf_counter() - t1
+        alg_tf = B * nsteps / el2 * gflop_per_image_step(H, W, C) * args.its / 1e3       # algorithmic TFLOP/s of the whole path
         out = dict(precision=mode, value=round(B * nsteps / el2, 4), steps=nsteps,
                    ms_per_step=round(1e3 * el2 / nsteps, 2), ms_per_iteration=round(1e3 * el2 / nsteps / args.its, 4),
-                   path_frac_of_fp32_mfma_peak=round(B * nsteps / el2 * gflop_per_image_step(H, W, C) * args.its / 1e3
-                                                     / FP32_MFMA_PEAK_TFLOPS, 4),
+                   algorithmic_tflops=round(alg_tf, 2),
                    hyper_branch_fork_point=codec2.fork_point(),
                    final_est_bpp_mean=float(met2[:, 4].mean()), final_psnr_mean=float(met2[:, 1].mean()),
                    note=NOTES[mode])
@@ -301,6 +306,25 @@ def main():
                 a2 = k2[0]["flops_total"] / (k2[0]["ms_total"] * 1e-3) / 1e12
                 out["dominant_kernel"] = dict(name=k2[0]["name"], algorithmic_tflops=round(a2, 2),
                                               avg_launch_us=round(1e3 * k2[0]["ms_total"] / k2[0]["launches"], 2))
+        if mode in PLANE_PRODUCTS_PER_MAC:
+            # the roofline of THIS mode (VERDICT r4 #3a): the pipe it runs on is the bf16 one, and it issues 6 (3) plane products
+            # per algorithmic MAC -- so achieved = algorithmic TFLOP/s x 6 (x 3) against 2.5 PF dense.  (The C -> 3 layer, the
+            # IGDN data-gradients and the elementwise kernels stay on the f32 pipe in these modes: the path figure slightly
+            # overstates the bf16 work; the dominant kernel's figure is exact for its convolution part.)
+            ppm = PLANE_PRODUCTS_PER_MAC[mode]
+            rl = dict(bound="mfma-bf16", peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s", plane_products_per_mac=ppm,
+                      achieved=round(alg_tf * ppm, 1), frac=round(alg_tf * ppm / BF16_MFMA_PEAK_TFLOPS, 4),
+                      sustained_on_random_operands=list(BF16_MFMA_SUSTAINED_RANDOM_TFLOPS),
+                      frac_of_sustained=[round(alg_tf * ppm / t, 4) for t in BF16_MFMA_SUSTAINED_RANDOM_TFLOPS],
+                      scope="whole path (value x algorithmic TFLOP per image x plane products)")
+            if "dominant_kernel" in out:
+                ak = out["dominant_kernel"]["algorithmic_tflops"] * ppm
+                rl["dominant_kernel"] = dict(name=out["dominant_kernel"]["name"], achieved=round(ak, 1),
+                                             frac=round(ak / BF16_MFMA_PEAK_TFLOPS, 4),
+                                             avg_launch_us=out["dominant_kernel"]["avg_launch_us"])
+            out["roofline"] = rl
+        else:
+            out["path_frac_of_fp32_mfma_peak"] = round(alg_tf / FP32_MFMA_PEAK_TFLOPS, 4)
         codec2.close()
         return out
 
@@ -342,6 +366,37 @@ def main():
             except Exception as e:      # measurement only: never fail the bench line for it
                 other_configs.append(dict(config=name, error=str(e)[:200]))
 
+    # ---- a TRAINED-LIKE operating point at the north star's width: the same workload with the model fitted by
+    # tests/tools/fit_weights.py (C = 192: 0.39 bpp / 33.5 dB one-shot; 87 % of y_hat at 0) on low-pass images -- the matrix
+    # pipe's clock depends on the operand data (155 TF on zeros, 142-148 on noise), and the synthetic weights end at 4 bpp
+    other_weights = None
+    fitted_path = os.path.join(ROOT, "tests", "golden", "fitted_weights_c%d.npz" % C)
+    if rank == 0 and world == 1 and args.steps and not args.no_other_configs and args.its >= 200 and os.path.exists(fitted_path):
+        try:
+            wf = sga_amd.load_weights_npz(fitted_path)
+            cdc = SGACodec(wf, C, B, H, W, device=device, precision=args.precision)
+            xf = torch.tensor(sga_amd.make_lowpass_images(B, H, W, seed=3000)).to(device)
+            cdc.run(xf, args.lmbda, its=110, seed=1, metrics=False)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            _, _, mf, _ = cdc.run(xf, args.lmbda, its=args.its, seed=2)
+            torch.cuda.synchronize(device)
+            el = time.perf_counter() - t1
+            yb, zb, mb = cdc.base_compress(xf, scale_bound=0.0)
+            other_weights = dict(weights="fitted_c%d (tests/golden/fitted_weights_c%d.npz), low-pass images" % (C, C),
+                                 value=round(B / el, 4), unit="images/sec", ms_per_iteration=round(1e3 * el / args.its, 4),
+                                 path_frac_of_fp32_mfma_peak=round(B / el * gflop_per_image_step(H, W, C) * args.its / 1e3
+                                                                   / FP32_MFMA_PEAK_TFLOPS, 4) if args.precision == "f32" else None,
+                                 hyper_branch_fork_point=cdc.fork_point(),
+                                 final_est_bpp_mean=float(mf[:, 4].mean()), final_psnr_mean=float(mf[:, 1].mean()),
+                                 one_shot_est_bpp_mean=float(mb[:, 4].mean()), one_shot_psnr_mean=float(mb[:, 1].mean()),
+                                 frac_zero_y_hat=float((yb == 0).float().mean()))
+            cdc.close()
+            del cdc, xf
+            torch.cuda.empty_cache()
+        except Exception as e:      # measurement only
+            other_weights = dict(error=str(e)[:200])
+
     tf_per_image = gflop_per_image_step(H, W, C) * args.its / 1e3
     path_frac = value / world * tf_per_image / FP32_MFMA_PEAK_TFLOPS
 
@@ -361,7 +416,7 @@ def main():
             "metric": "images/sec for 2000-step SGA (num_filters=192, 256x256) + final BPP/PSNR match",
             "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (3 x bf16 exact operand split, f32 accumulate)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else ("f32 (3 x bf16 exact operand split, f32 accumulate)" if args.precision == "bf16x3" else "bf16x2 (operands rounded to 16 mantissa bits, f32 accumulate)"),
             "data": "synthetic",
             "config": {"workload": f"sga.py {args.its}-step SGA, num_filters={C}, lambda={args.lmbda}, "
                                    f"batch of {B} synthetic {H}x{W} images per GPU",
@@ -376,6 +431,7 @@ def main():
             "alt_precision": alt,
             "fast_precision": fast,
             "other_configs": other_configs,
+            "other_weights": other_weights,
             "path_frac_of_fp32_mfma_peak": round(path_frac, 4),
             "tflop_per_image": round(tf_per_image, 3),
             "final_est_bpp_mean": float(np.mean(m[:, 4])), "final_psnr_mean": float(np.mean(m[:, 1])),

@@ -102,22 +102,31 @@ struct Col2imMse {
 // global memory -- 3 floats from each of up to 9 rows 320 bytes apart per thread -- ran at 47 us: 27 load
 // instructions per wave, each touching 32 cache lines.)
 constexpr int CT_H = 8, CT_W = 8, CH_H = CT_H + 2, CH_W = CT_W + 2, CPOS = CH_H * CH_W;
+// LDS pitch of a position's products.  Lanes of one parity class read the SAME column offset of positions hx, hx + 1, ...:
+// at a pitch of 80 floats (= 16 banks mod 32) positions two apart collide -- 38.7 % LDS bank conflicts, 73 % wait
+// (profiles/r04_pmc_kernels.txt).  Only 75 of the 80 columns carry products: 19 of the 20 row pieces are staged at a pitch of
+// 76 floats = 12 mod 32, which puts eight consecutive positions on eight different bank groups (0, 12, 24, 4, 16, 28, 8, 20),
+// keeps the 16-byte alignment of the pieces and the 5 workgroups per CU (30.4 KB)
+#ifndef SGA_COL2IM_PITCH
+#define SGA_COL2IM_PITCH 76
+#endif
+constexpr int CPITCH = SGA_COL2IM_PITCH, CPIECES = CPITCH < NCOL ? CPITCH / 4 : NCOL / 4;
 
 template <bool MSE>
 __global__ __launch_bounds__(256) void deconv3_col2im_kernel(const float* __restrict__ P, const float* __restrict__ bias,
                                                              float* __restrict__ out, int Hi, int Wi, int Ho, int Wo,
                                                              int tiles_x, Col2imMse ms) {
-  __shared__ __attribute__((aligned(16))) float Ps[CPOS * NCOL];
+  __shared__ __attribute__((aligned(16))) float Ps[CPOS * CPITCH];
   __shared__ double red[8];
   const int b = blockIdx.y;
   const int ty0 = (blockIdx.x / tiles_x) * CT_H, tx0 = (blockIdx.x % tiles_x) * CT_W;
-  for (int f = threadIdx.x; f < CPOS * (NCOL / 4); f += 256) {
-    const int pos = f / (NCOL / 4), c4 = f - pos * (NCOL / 4);
+  for (int f = threadIdx.x; f < CPOS * CPIECES; f += 256) {
+    const int pos = f / CPIECES, c4 = f - pos * CPIECES;
     const int i = ty0 + pos / CH_W - 1, j = tx0 + pos % CH_W - 1;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if ((unsigned)i < (unsigned)Hi && (unsigned)j < (unsigned)Wi)
       v = *reinterpret_cast<const f32x4*>(P + ((size_t)(b * Hi + i) * Wi + j) * NCOL + c4 * 4);
-    *reinterpret_cast<f32x4*>(&Ps[pos * NCOL + c4 * 4]) = v;
+    *reinterpret_cast<f32x4*>(&Ps[pos * CPITCH + c4 * 4]) = v;
   }
   __syncthreads();
   float a0 = 0.f, a1 = 0.f;
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(256) void deconv3_col2im_kernel(const float* __rest
         const int kx = (lx & 1) + 2 * c;
         if (kx > 4) continue;
         const int hx = ((lx - kx + 2) >> 1) + 1;
-        const float* t = &Ps[(hy * CH_W + hx) * NCOL + (ky * 5 + kx) * 3];
+        const float* t = &Ps[(hy * CH_W + hx) * CPITCH + (ky * 5 + kx) * 3];
         s0 += t[0]; s1 += t[1]; s2 += t[2];
       }
     }
