@@ -1022,6 +1022,12 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
   // output rows (coalesced float4 stores and aux loads instead of 4-byte column scatters).
   const int epi = a.ksplit > 1 ? -1 : a.epi;      // split-K: raw partial sums, epilogue in the reduce
   float* const outp = a.ksplit > 1 ? a.part + (size_t)split * a.slab : a.out;
+  // (laboratory build only: the in-launch slab sum is correct -- bit-equal to the reduce launches at seven shapes -- and SLOWER:
+  //  +85 us per iteration at cfg 2 with every split fused, +0..10 us with only the <= 8-slab launches; DESIGN_EXPERIMENTS.md A.10)
+#ifdef SGA_EXPERIMENTS
+  const bool fuse_reduce = a.ksplit > 1 && a.tickets != nullptr;
+  const __amdgpu_buffer_rsrc_t part_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, 0x7ffffff0, 0x00020000);
+#endif
   float* Cs = smem + (LOWF ? (wid & 1) : wid) * (32 * CPITCH);
   constexpr int F4_PER_ROW = TN * 8;
   constexpr int F4_ITERS = (32 * F4_PER_ROW) / 64;
@@ -1081,13 +1087,71 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
         default:
           break;
       }
-      *reinterpret_cast<f32x4*>(outp + o) = v;
+#ifdef SGA_EXPERIMENTS
+      if (fuse_reduce) {
+        // write-through (sc1): the slab must be visible to a workgroup on another XCD without a release fence that would
+        // write back the whole L2 (MI355X_MICROARCH.md, publish-large: 3.0 against 8.2 us per 64 KB)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), part_rsrc,
+                                               (int)((((size_t)split * (size_t)a.slab) + o) * sizeof(float)), 0, 16);
+      } else
+#endif
+      {
+        *reinterpret_cast<f32x4*>(outp + o) = v;
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
   }
   if constexpr (LOWF) __syncthreads();
   }
+#ifdef SGA_EXPERIMENTS
+  if (fuse_reduce) {
+    // ---- ticket: the last workgroup of this output tile sums its slabs (fixed order) and applies the epilogue ----------
+    __shared__ __attribute__((aligned(16))) int sk_last[4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0) {
+      unsigned* const tk = a.tickets + (size_t)phase * a.tiles_per_phase * a.ntiles_n + (size_t)mt * a.ntiles_n + nt;
+      const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = t == (unsigned)(nsplit - 1);
+      if (last) {
+        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // this CU's L1 may hold the previous iteration's slabs
+      }
+      sk_last[0] = last;
+    }
+    __syncthreads();
+    if (sk_last[0]) {
+      constexpr int F4R = BN / 4;
+      for (int f = tid; f < BM * F4R; f += NT) {
+        const int row = f / F4R, c4 = f - row * F4R;
+        const long long px = rowpix[row];
+        const int n = n0 + c4 * 4;
+        if (px < 0 || n >= a.Cout) continue;
+        const size_t o = (size_t)px * a.out_cs + a.out_coff + n;
+        f32x4 sum = ld4(a.part + o);
+        for (int s0 = 1; s0 < nsplit; s0 += 8) {                  // loads 8 at a time, adds in the order 1, 2, ... (= splitk_reduce_kernel)
+          f32x4 v8[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v8[k] = ld4(a.part + (size_t)(s0 + k < nsplit ? s0 + k : nsplit - 1) * a.slab + o);
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (s0 + k < nsplit) sum += v8[k];
+        }
+        if ((a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU) && a.bias) sum += ld4(a.bias + n);
+        if (a.epi == EPI_BIAS_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum[e] = fmaxf(sum[e], 0.f);
+        } else if (a.epi == EPI_RELU_MASK) {
+          const f32x4 mk = ld4(a.aux0 + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum[e] = mk[e] > 0.f ? sum[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(a.out + o) = sum;
+      }
+    }
+  }
+#endif
   SGA_PROBE_END();
 }
 

@@ -85,6 +85,11 @@ struct sga_handle {
   struct ClkSlot { char name[96]; int grid; };
   std::vector<ClkSlot> clk_slots;
   unsigned* ticket = nullptr;      // k_step_boundary's last-workgroup counter (zero between launches)
+  // split-K slab sums inside the convolution launch (conv_mfma.hip, ConvArgs::tickets): one zeroed counter per output tile, a
+  // set per concurrently running branch.  fuse_reduce: bit 0 = main chain, bit 1 = hyper branch (SGA_FUSE_REDUCE, laboratory)
+  unsigned* sk_tickets[2] = {nullptr, nullptr};
+  static constexpr int kTickets = 8192;
+  int fuse_reduce = 0;             // (off: correct and slower, DESIGN_EXPERIMENTS.md A.10)
   unsigned* ws_sched = nullptr;    // igdn_bwd_ws_kernel's shared tile counter + exit counter (zero between launches)
   int igdn_ws = 0;                 // SGA_IGDN_WS (laboratory build): 0 = igdn2.bwd on gdn_tile_kernel (default), 1 = on the persistent wave-specialised kernel of
                                    //   igdn_bwd_ws.hip when the launch has >= 2 tiles per CU, 2 = whenever its shape is supported (tests).
@@ -483,6 +488,20 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     a.x3w4 = (w4 && a.x3 == 1 && a.bm == 256 && !a.post) ? 1 : 0; }
   const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
   if (a.ksplit > 1) { a.part = h->cur_part->p; a.slab = n_out; }
+  // the slab sum inside the launch (last arriver of every output tile) instead of a reduce launch, where nothing else consumes
+  // the slabs: removes the six reduce launches of the hyper branch and the one after gs0.bwd (round 5)
+  a.tickets = nullptr;
+#ifdef SGA_EXPERIMENTS
+  if (a.ksplit > 1 && !defer) {
+    const int which = (h->cur_part == &h->partB) ? 1 : 0;
+    const long long tiles_all = (long long)a.nphase * a.tiles_per_phase * a.ntiles_n;
+    const bool ok = (h->fuse_reduce >> which) & 1;
+    static const int max_s = LAB_ENV("SGA_FUSE_REDUCE_MAXS") ? atoi(LAB_ENV("SGA_FUSE_REDUCE_MAXS")) : 8;      // the last arriver sums ALONE
+    if (ok && a.ksplit <= max_s && h->sk_tickets[which] && tiles_all <= sga_handle::kTickets && (long long)a.ksplit * n_out * 4 < 0x7ffffff0LL &&
+        (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RELU_MASK))
+      a.tickets = h->sk_tickets[which];
+  }
+#endif
   bool gprof_here = false;
   if (h->gprof && !h->gprof_in_graph) {
     hipStreamCaptureStatus gcs = hipStreamCaptureStatusNone;
@@ -549,7 +568,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
       if (a.s_out != 2) for (int p = 1; p < 4; ++p) defer->nsplit[p] = defer->nsplit[0];
     }
   }
-  if (a.ksplit > 1 && !defer) HIPCHK(h, launch_splitk_reduce(a, n_out, st));
+  if (a.ksplit > 1 && !defer && !a.tickets) HIPCHK(h, launch_splitk_reduce(a, n_out, st));
   if (h->profiling && h->profile_by_layer) {    // layer-level stats: conv + its reduce
     HIPCHK(h, hipEventRecord(r.b, st));
     h->prof.push_back(r);
@@ -1676,6 +1695,11 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     TRY(dev_alloc(h, &p, 256));
     if (hipMemset(p, 0, 256) != hipSuccess) return fail(SGA_ERR_HIP);
     h->ws_sched = (unsigned*)p;
+    for (int k = 0; k < 2; ++k) {
+      TRY(dev_alloc(h, &p, sizeof(unsigned) * sga_handle::kTickets));
+      if (hipMemset(p, 0, sizeof(unsigned) * sga_handle::kTickets) != hipSuccess) return fail(SGA_ERR_HIP);
+      h->sk_tickets[k] = (unsigned*)p;
+    }
   }
   {
     void* p = nullptr;
@@ -1814,6 +1838,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->fused_mse = !(env && env[0] == '0');
   env = getenv("SGA_NO_SPLITK");
   h->no_splitk = env && env[0] == '1';
+  env = LAB_ENV("SGA_FUSE_REDUCE");
+  if (env) h->fuse_reduce = atoi(env);
   env = LAB_ENV("SGA_IGDN_WS");
   if (env) h->igdn_ws = atoi(env);
   env = LAB_ENV("SGA_IGDN_WS_SCHED");

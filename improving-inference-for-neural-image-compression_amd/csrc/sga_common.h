@@ -126,6 +126,11 @@ struct ConvArgs {
   int blk_begin[4];        //   gets splits in proportion and all workgroups walk ~equal K
   long long slab;
   float* part;
+  // split-K with the slab sum INSIDE the launch (round 5): every workgroup stores its slab write-through, takes a ticket of its
+  // output tile, and the LAST arriver sums the tile's slabs in the fixed order 0, 1, ... and applies the epilogue -- what
+  // splitk_reduce_kernel does, bit for bit, without a launch.  tickets: one zeroed counter per (phase, tile), reset by the
+  // last arriver; null: slabs only (a reduce launch or the consuming GDN kernel sums them)
+  unsigned* tickets;
   ConvPhase ph[4];
   ConvTap taps[28];
 };
