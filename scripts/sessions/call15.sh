@@ -2,7 +2,7 @@
 # crash hunt 2 (A.8a): FULL collection (every test module imported), the tests up to the crashing one, destroy policy, the lab
 # build with its SIGSEGV handler (native frames through backtrace_symbols_fd)
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/call15; mkdir -p $OUT
 export GPU_MAX_HW_QUEUES=2
 LAB=$PWD/improving-inference-for-neural-image-compression_amd/libsga_hip_lab.so

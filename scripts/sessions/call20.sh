@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: what the driver runs at round end -- the GPU suite, smoke(), the default bench line
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/call20; mkdir -p $OUT
 {
 echo "=== pytest -m gpu"

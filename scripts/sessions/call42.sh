@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU box: what the driver runs at round end -- the GPU suite, smoke(), the default bench line
 set -u
-cd "$(dirname "$0")/.."
-OUT=gpurun_out/call37; mkdir -p $OUT
+cd "$(dirname "$0")/../.."
+OUT=gpurun_out/call42; mkdir -p $OUT
 {
 echo "=== pytest -m gpu"
 timeout 2700 python -X faulthandler -m pytest tests/ -x -q -m gpu > $OUT/tests.log 2>&1; echo "rc $?" >> $OUT/tests.log; tail -6 $OUT/tests.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/call6; mkdir -p $OUT
 export GPU_MAX_HW_QUEUES=2
 LAB=$PWD/improving-inference-for-neural-image-compression_amd/libsga_hip_lab.so

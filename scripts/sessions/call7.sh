@@ -2,7 +2,7 @@
 # crash hunt (DESIGN_EXPERIMENTS.md A.8): the test files up to test_gpu_configs in one process, destroy policy, core dumps on,
 # repeated; a core is opened with rocgdb for the native backtrace of every thread.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/call7; mkdir -p $OUT
 export GPU_MAX_HW_QUEUES=2

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/call9; mkdir -p $OUT
 export GPU_MAX_HW_QUEUES=2
 step() { echo "=== $*" | tee -a $OUT/summary.log; }
