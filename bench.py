@@ -302,6 +302,10 @@ def main():
             codec2.profile_begin()
             codec2.run(x, args.lmbda, its=min(args.its, 60), seed=7, metrics=False)
             k2 = sorted(codec2.profile_end(), key=lambda k: -k["ms_total"])
+            # the same LAUNCH as the f32 roofline's (gs2.fwd + IGDN: the 256-row instance with the post-phase), not the symbol
+            # with the largest total -- in the bf16 modes that is the 64-row instance summed over its 9 launches per iteration
+            big = [k for k in k2 if k["name"].replace(" ", "").startswith("conv_mfma_kernel<2,3,4,2") and k["name"].replace(" ", "").endswith(",1>")]
+            k2 = (big or k2)[:1] + [k for k in k2 if k not in (big or k2)[:1]]
             if k2:
                 a2 = k2[0]["flops_total"] / (k2[0]["ms_total"] * 1e-3) / 1e12
                 out["dominant_kernel"] = dict(name=k2[0]["name"], algorithmic_tflops=round(a2, 2),
@@ -379,7 +383,7 @@ def main():
             cdc.run(xf, args.lmbda, its=110, seed=1, metrics=False)
             torch.cuda.synchronize(device)
             t1 = time.perf_counter()
-            _, _, mf, _ = cdc.run(xf, args.lmbda, its=args.its, seed=2)
+            yf, _, mf, _ = cdc.run(xf, args.lmbda, its=args.its, seed=2)
             torch.cuda.synchronize(device)
             el = time.perf_counter() - t1
             yb, zb, mb = cdc.base_compress(xf, scale_bound=0.0)
@@ -390,7 +394,7 @@ def main():
                                  hyper_branch_fork_point=cdc.fork_point(),
                                  final_est_bpp_mean=float(mf[:, 4].mean()), final_psnr_mean=float(mf[:, 1].mean()),
                                  one_shot_est_bpp_mean=float(mb[:, 4].mean()), one_shot_psnr_mean=float(mb[:, 1].mean()),
-                                 frac_zero_y_hat=float((yb == 0).float().mean()))
+                                 frac_zero_y_hat=float((yf == 0).float().mean()))
             cdc.close()
             del cdc, xf
             torch.cuda.empty_cache()

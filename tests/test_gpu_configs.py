@@ -306,12 +306,12 @@ def test_full_bits_back_run_cfg5_kodak():
     stage 2 lowers the rate objective it optimises."""
     from sga_amd.codec import SGACodec, metrics_to_dict
     C, B, H, W = 192, 1, 512, 768
-    w = dict(sga_amd.make_synthetic_weights(C, seed=0, bb=True))
-    # the untrained synthetic h_a emits |z_mean|, |z_logvar| ~ 20 at this image size, where exp(.) of the
-    # predicted log-scale overflows float32 (here as it would in TF); a trained model keeps them O(1)
-    w["ha.k2"] = (w["ha.k2"] * 0.05).astype(np.float32)
+    # round 5: the bits-back model FITTED at C = 192 (FIT_C=192 tests/tools/fit_weights.py 3000 bb; posterior log-variances O(1)).
+    # Rounds 2-4 ran this test on the untrained synthetic h_a with its last kernel scaled by 0.05, because that model emits
+    # |z_mean|, |z_logvar| ~ 20 at this image size and exp(.) of the predicted log-scale overflows float32 (as it would in TF).
+    w = sga_amd.load_weights_npz(os.path.join(os.path.dirname(__file__), "golden", "fitted_weights_c192bb.npz"))
     codec = SGACodec(w, C, B, H, W, bits_back=True)
-    x = np.random.RandomState(23).rand(B, H, W, 3).astype(np.float32)
+    x = sga_amd.make_lowpass_images(B, H, W, seed=23)
     a = codec.bb_run(x, 0.01, its=2000, r_its=2000, seed=4, trace=True)
     b = codec.bb_run(x, 0.01, its=2000, r_its=2000, seed=4, trace=True)
     assert torch.isfinite(a[1]).all()
