@@ -1160,6 +1160,7 @@ struct ReduceArgs {
   int cout, epi, hout, wout, s_out;
   int nsplit[4];
   const float* bias; const float* aux0; float* out;
+  int side;      // the launch belongs to the hyper branch (SGA_SIDE_ELEM_PRIO)
 };
 
 // BATCH: the loads of 8 slabs are issued together and only the adds are serial (same order, same result).  A
@@ -1168,6 +1169,9 @@ struct ReduceArgs {
 // `hs2.bwd` ready exactly when `gs2.fwd` starts and the ITERATION 70 us slower.
 template <bool BATCH>
 __global__ void splitk_reduce_kernel(const ReduceArgs r) {
+#if SGA_SIDE_ELEM_PRIO
+  if (r.side) __builtin_amdgcn_s_setprio(SGA_SIDE_ELEM_PRIO);
+#endif
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < r.n4;
        i += (long long)gridDim.x * blockDim.x) {
     const long long e = i * 4;
@@ -1306,7 +1310,7 @@ int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream) {
   r.cout = a.Cout; r.epi = a.epi; r.hout = a.Hout; r.wout = a.Wout; r.s_out = a.s_out;
   for (int p = 0; p < 4; ++p) r.nsplit[p] = a.nsplit[p] > 0 ? a.nsplit[p] : 1;
   // the phase table is ordered heaviest-first == (py,px) = (0,0),(0,1),(1,0),(1,1): index py*2+px
-  r.bias = a.bias; r.aux0 = a.aux0; r.out = a.out;
+  r.bias = a.bias; r.aux0 = a.aux0; r.out = a.out; r.side = a.side;
   long long g = (r.n4 + 255) / 256;
   if (g > 4096) g = 4096;
   if (g < 1) g = 1;

@@ -268,6 +268,9 @@ __global__ void k_factorized(const float* __restrict__ zt, const float* __restri
                              float inv_ln2_hw, ImgSums* __restrict__ sums,
                              float* __restrict__ g_zt, float* __restrict__ p_out,
                              float* __restrict__ dp_out) {
+#if SGA_SIDE_ELEM_PRIO
+  __builtin_amdgcn_s_setprio(SGA_SIDE_ELEM_PRIO);
+#endif
   __shared__ double sh[16];
   const int b = blockIdx.y;
   const float ls = ctx ? ctx->loss_scale : 1.0f;
@@ -409,6 +412,9 @@ __global__ void k_gaussian(const float* __restrict__ yt, const float* __restrict
                            const StepCtx* __restrict__ ctx, int h, int w, int hs, int ws, int C,
                            float inv_ln2_hw, float smin, ImgSums* __restrict__ sums,
                            float* __restrict__ g_yt, float* __restrict__ g_ms) {
+#if SGA_SIDE_ELEM_PRIO
+  __builtin_amdgcn_s_setprio(SGA_SIDE_ELEM_PRIO);
+#endif
   __shared__ double sh[16];
   const int b = blockIdx.y;
   const float ls = ctx->loss_scale;

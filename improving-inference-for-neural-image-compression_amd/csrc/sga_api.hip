@@ -438,6 +438,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   a.ksplit = pick_ksplit(h, a);
   a.zeros = h->zeros;
   a.prio = (h->cur_part == &h->partB) ? h->side_wave_prio : h->main_wave_prio;
+  a.side = h->in_hyper ? 1 : 0;
   a.lowfoot = (h->in_hyper && h->side_lowfoot && a.bm == 64 && !a.post && !a.smallc && a.pro == PRO_NONE && !h->x3) ? 1 : 0;
 #ifdef SGA_CLOCK_PROBE
   a.clk = (h->clk_mode == 1 && h->profiling && h->profile_by_layer) ? h->clk_probe : nullptr;

@@ -117,6 +117,7 @@ struct ConvArgs {
   int reduce_batch;        // split-K reduce: issue the slab loads 8 at a time (main chain) or one by one
   int lowfoot;             // 64-row instance in its low-footprint form (one LDS stage, 33 KB): hyper branch, SGA_SIDE_LOWFOOT=1
   int prio;                // wave priority (s_setprio) for the whole launch: experiment, SGA_MAIN_WAVE_PRIO / SGA_SIDE_WAVE_PRIO
+  int side;                // the launch belongs to the hyper branch (its split-K reduce: SGA_SIDE_ELEM_PRIO)
   int xcd_remap;           // unsplit launch, tiles_per_phase % 8 == 0: XCD x (blocks b % 8 == x) walks a contiguous eighth of every
                            //   phase's M tiles, so that the taps' re-gathers of one input region meet in ONE 4 MiB L2
   int pair_phases;         // 4-phase launch whose whole grid is resident at once: walk the phases as 9,6,4,6 taps
@@ -158,6 +159,11 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len);
 #define SGA_NT 15
 #endif
 #define SGA_IGDN_NT (SGA_NT & 3)
+// Wave priority of the hyper branch's small kernels (k_factorized, k_gaussian, the split-K reduces): they run beside the main chain's
+// MFMA kernels, whose older waves win the issue arbitration -- k_gaussian takes 97 us in the graph against 9 alone.  0: off
+#ifndef SGA_SIDE_ELEM_PRIO
+#define SGA_SIDE_ELEM_PRIO 0
+#endif
 enum GdnMode { GDN_IGDN_FWD = 0, GDN_GDN_FWD = 1, GDN_IGDN_BWD = 2 };
 enum GdnPrologue { GDN_PRO_LOAD = 0, GDN_PRO_CONV3 = 1 };
 struct GdnArgs {
