@@ -10,7 +10,7 @@
 #    GaussianConditional._likelihood (on an UN-called and on a called layer), RelaxedOneHotCategorical.sample with injected
 #    uniforms and tf.image.ssim_multiscale -> tests/golden/tf_ops_reference.npz;
 # 3. prints which sigma-bound mode the un-called layer executed (the PROVISIONAL default of include/sga_hip.h);
-# 5. LAST: scripts/first_contact_report.py writes profiles/first_contact_report.json (sigma-bound mode observed, per-operator
+# 5. LAST: tests/tools/first_contact_report.py writes profiles/first_contact_report.json (sigma-bound mode observed, per-operator
 #    maximum error oracle-vs-TF and HIP-vs-TF, the checkpoint's variable names against the importer's) -- the ONE file to
 #    commit: it turns SURVEY.md 8(c) and `parity` from "partial" to pinned.
 # 4. runs the consumers in THIS repo's environment: tests/test_tf_reference.py (oracle on CPU; HIP path with -m gpu) and, when
@@ -62,5 +62,5 @@ for C in (192, 256, 128):
         print("num_filters = %d: %s" % (C, e))
 PY
 fi
-python scripts/first_contact_report.py tests/golden/tf_ops_reference.npz ${CKPT:+"$CKPT"}
+python tests/tools/first_contact_report.py tests/golden/tf_ops_reference.npz ${CKPT:+"$CKPT"}
 echo "commit tests/golden/tf_ops_reference.npz and profiles/first_contact_report.json"

@@ -1,4 +1,4 @@
-"""Last step of scripts/first_contact_tf.sh: ONE file that turns SURVEY.md 8(c) / `parity` from "partial" to pinned.
+"""(Test infrastructure: it runs the oracle as the checker.)  Last step of scripts/first_contact_tf.sh: ONE file that turns SURVEY.md 8(c) / `parity` from "partial" to pinned.
 
 Runs in THIS repo's environment (no TensorFlow needed) on the fixture scripts/make_golden_from_tf.py wrote on a TF 1.15 /
 tfc 1.3 / tfp 0.7.0 box (tests/golden/tf_ops_reference.npz) and writes profiles/first_contact_report.json:
@@ -12,13 +12,13 @@ tfc 1.3 / tfp 0.7.0 box (tests/golden/tf_ops_reference.npz) and writes profiles/
   * with a checkpoint directory (argument 2 or SGA_TF_CHECKPOINT): the bundle's variable names and shapes next to what
     sga_amd/tf_checkpoint.py expects, and whether the effective weights load.
 
-    python scripts/first_contact_report.py [fixture.npz] [checkpoint_dir]        # commit profiles/first_contact_report.json
+    python tests/tools/first_contact_report.py [fixture.npz] [checkpoint_dir]        # commit profiles/first_contact_report.json
 """
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
