@@ -70,6 +70,33 @@ def test_step_at_config_shape(C, H, W, f64, sb, precision, gpu_out_dir):
     codec.close()
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_step_at_tecnick_size_trained_like_weights(precision, gpu_out_dir):
+    """The conditioning note of the test above, checked from the other side: with a TRAINED-LIKE model -- the
+    C = 192 weights fitted by tests/tools/fit_weights.py: predicted scales 0.087 (1 %) .. 0.098 (median) .. 6, never 7e-4 -- the
+    raw-sigma step (sga.py:130-133) at Tecnick size (1200 x 1200: ragged 75 x 75 latents, crops live) needs NO looser tolerance
+    against the float32 oracle: 1 / sigma <= 12, so the float32 rounding of mu moves a gradient by 1e-5, not 1e-3."""
+    from sga_amd.codec import SGACodec
+    C, H, W = 192, 1200, 1200
+    w = sga_amd.load_weights_npz(os.path.join(os.path.dirname(__file__), "golden", "fitted_weights_c192.npz"))
+    x = sga_amd.make_lowpass_images(1, H, W, seed=41)
+    orc = SGAOracle(w, dtype=torch.float32, scale_bound=0.0)
+    codec = SGACodec(w, C, 1, H, W, precision=precision, scale_bound=0.0)
+    yo, zo = orc.encode(x)
+    y, z = codec.encode(x)
+    assert rel_err(y.cpu().numpy(), yo.numpy()) < 2e-5 and rel_err(z.cpu().numpy(), zo.numpy()) < 2e-5
+    seed, it, T, lmbda = 9, 3, 0.3, 0.01
+    u_y = philox.sga_uniforms(yo.numel(), it, 0, seed)
+    u_z = philox.sga_uniforms(zo.numel(), it, 1, seed)
+    want = orc.step(x, yo, zo, T, u_y, u_z, lmbda)
+    got = codec.step_grads(x, yo.numpy(), zo.numpy(), T, lmbda, seed=seed, it=it)
+    errs = dict(gy=rel_err(got["gy"].cpu().numpy(), want["gy"].numpy()), gz=rel_err(got["gz"].cpu().numpy(), want["gz"].numpy()),
+                rd_loss=abs(float(got["rd_loss"]) / float(want["rd_loss"]) - 1))
+    report(gpu_out_dir, test="config_step_fitted_c192_tecnick", C=C, H=H, W=W, precision=precision, scale_bound=0.0, **errs)
+    assert errs["gy"] < 1e-4 and errs["gz"] < 5e-4 and errs["rd_loss"] < 1e-5, errs      # the NON-ill bounds of the test above
+    codec.close()
+
+
 @pytest.mark.parametrize("C,H,W,f64", [(192, 512, 768, True), (256, 1200, 1200, False), (256, 96, 80, True)])
 def test_step_at_config_shape_bf16x2(C, H, W, f64, gpu_out_dir):
     """The fast precision mode (two bf16 planes per convolution operand) at the cfg-3 / cfg-4 shapes, incl. the 256-wide tiles of
