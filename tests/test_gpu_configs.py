@@ -428,6 +428,25 @@ def test_graph_cache_selects_instead_of_recapturing():
     codec.close()
 
 
+def test_graph_cache_eviction_keeps_results():
+    """More distinct keys than the cache holds (16): the least recently used entries are retired (kept until sga_destroy under the
+    default policy), and a retired key that comes back is simply captured again -- every run stays bit-identical to its first."""
+    from sga_amd.codec import SGACodec
+    C = 64
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    codec = SGACodec(w, C, 2, 96, 96)
+    geos = [(b, hh, ww) for b in (1, 2) for hh in (48, 64, 96) for ww in (48, 64, 96)]          # 18 keys
+    xs = [np.random.RandomState(30 + i).rand(b, hh, ww, 3).astype(np.float32) for i, (b, hh, ww) in enumerate(geos)]
+    first = [codec.run(x, 0.01, its=14, seed=2) for x in xs]
+    assert codec.counter("captures") == 18 and codec.counter("cached") == 16 and codec.counter("evictions") == 2
+    again = [codec.run(x, 0.01, its=14, seed=2) for x in xs]             # keys 0, 1 were evicted: re-captured, evicting others in turn
+    for a, b in zip(first, again):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert codec.counter("cached") == 16 and codec.counter("evictions") >= 4
+    assert codec.counter("retired") == codec.counter("evictions")        # short runs: no fork-point candidates were timed
+    codec.close()
+
+
 def test_base_compress_inside_an_open_run():
     """the one-shot encode (mbt2018.py:64-81) used h->y / h->z -- the live latents of a run opened by sga_run_begin --
     as temporaries.  It encodes into scratch now: called between two sga_run_steps calls it returns what it returns on an idle
