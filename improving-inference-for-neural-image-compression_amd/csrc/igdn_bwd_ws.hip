@@ -12,14 +12,18 @@
 //                fragment order: a wave-load is 1 KB contiguous), prefetched PF steps ahead, so their K loops contain
 //                no barrier and no LDS write; the A operand of the contraction is resident in LDS, the A operand of the
 //                gradient convolution is gathered from the (L2-resident) gradient image.
-//   waves 4..7   "memory" waves: every HBM byte.  They turn the matrix waves' g tile into the contraction operand
+//   waves 4..11  "memory" waves (WS_LW_N = 8; 4 with 256 registers per wave measured slower): every HBM byte.  They turn the matrix waves' g tile into the contraction operand
 //                g u / s IN PLACE in LDS (reading v, s once, keeping g s and u = v / s in registers) and later combine
 //                those registers with the contraction result into g_u = g s + u (A . gamma) and store it.
 //
 //   phase p of a workgroup (tiles i = 0, 1, ... taken from a shared counter; three rotating LDS buffers X[i % 3]):
 //     matrix:  conv3(i = p + 2) -> acc | Ba | acc -> X[(p+2)%3] ;  contract(i = p) from X[p%3] -> acc | Bb | acc -> X[p%3] | Bc
-//     memory:  epilogue(i = p - 1) from X[(p-1)%3]; request v, s of tile p + 1 | Ba | fill(i = p + 1) in X[(p+1)%3] | Bb | Bc
+//     memory:  epilogue(i = p - 1) from X[(p-1)%3] | Ba | request v, s of tile p + 1; fill(i = p + 1) in X[(p+1)%3] | Bb | Bc
 //   ((p+2) % 3 == (p-1) % 3: the gradient tile of i = p + 2 lands in the buffer the epilogue of i = p - 1 has just left.)
+//
+// LABORATORY BUILD ONLY (csrc/Makefile): measured 144.5 us alone against 148.3 for the tile kernel and +20 us inside the iteration
+// (one 150-KB workgroup per CU leaves no LDS for the hyper branch's kernels); what its in-kernel stamps say about L2 latency under
+// load and about the two roles sharing one vector-memory pipe: DESIGN_EXPERIMENTS.md A.11.  Harness: scripts/r05/igdn_ws_bench.hip.
 //
 // Arithmetic and summation order are those of gdn_tile_kernel<NC,2,2,GDN_IGDN_BWD,GDN_PRO_CONV3> (same 32 x 96 blocks per
 // wave, same K order, same elementwise expressions): results are bit-identical (tests/test_gpu_fused.py).
