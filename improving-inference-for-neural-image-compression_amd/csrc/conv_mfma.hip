@@ -83,7 +83,7 @@ constexpr bool glds_instance(int TM, int TN, int WM, int WN, int PRO, bool SMALL
   // 2-wave BN = 96 instance of the hyper branch (same speed alone, but with 56 KB per workgroup it gets in the
   // main chain's way: the iteration measured 1868 against 1827 us)
   return !X3 && !SMALLC && PRO == PRO_NONE &&
-         (((POST <= 1 || POST == 3) && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2) ||
+         (((POST <= 1 || POST == 3 || POST == 4) && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2) ||
           (TM == 2 && TN == 4 && WM == 4 && WN == 2));
 }
 
@@ -130,15 +130,20 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
   // epilogue staged two waves at a time -> 33 KB instead of 64.5 KB, so that a workgroup fits beside a 117-KB workgroup of the
   // 256-row instance (gs2.bwd holds every CU from start to end; the branch's backward half otherwise waits for it)
   constexpr bool LOWF = POST == 3;
+  // POST = 4: the DEEP form of the 64-row instance (round 5): FOUR LDS stages (128 KB, one workgroup per CU) and counted vmcnt
+  // waits, for launches whose grid cannot put two or three workgroups on every CU (the 16^2 ... 32^2 stages, B = 1): with two
+  // stages a step's DMA has one step of one workgroup to land, and a 10-step K chain runs at the L2 latency, not at the MFMA rate
+  constexpr bool DEEP = POST == 4;
+  constexpr int GSTAGES = DEEP ? 4 : (LOWF ? 1 : 2);
   constexpr bool HASPOST = POST == 1 || POST == 2;
   constexpr bool X3P = x3_pipelined(PRO, SMALLC, X3);
-  constexpr int MAIN_FLOATS = X3 ? x3_main_floats(BM, BN, X3P) : (GLDS ? (LOWF ? 1 : 2) * (BM + BN) * 32 : (BM + BN) * LDK);
+  constexpr int MAIN_FLOATS = X3 ? x3_main_floats(BM, BN, X3P) : (GLDS ? GSTAGES * (BM + BN) * 32 : (BM + BN) * LDK);
   constexpr int EPI_FLOATS = (LOWF ? 2 : WM * WN) * 32 * CPITCH;
   constexpr int POST_FLOATS = HASPOST ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
   constexpr int LDS_FLOATS0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   constexpr int LDS_FLOATS = LDS_FLOATS0 > POST_FLOATS ? LDS_FLOATS0 : POST_FLOATS;
   static_assert(!POST || (((BM == 256 && (BN == 192 || BN == 256) && NT == 512 && TM == 2 && HASPOST) ||
-                           (BM == 64 && BN == 192 && NT == 256 && TM == 1 && (POST == 1 || POST == 3))) && !SMALLC && PRO == PRO_NONE),
+                           (BM == 64 && BN == 192 && NT == 256 && TM == 1 && (POST == 1 || POST == 3 || POST == 4))) && !SMALLC && PRO == PRO_NONE),
                 "post-phase instance");
   constexpr int PBX = X3 ? (BN * 12 + NT - 1) / NT : 1;     // 16-byte pieces of the 3-plane weight tile per thread
   constexpr bool PBX_TAIL = X3 && (BN * 12) % NT != 0;       // ... the last round covers part of the threads (8 waves x BN = 192)
@@ -550,6 +555,57 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
       for (int p = 0; p < IB; ++p)
         dma16_to_lds(gb_src[p] + ci, st + lds_b + p * 256);
     };
+    if constexpr (DEEP) {
+      // stage ks lives in slot (ks - k_begin) % 4.  Iteration ks: wait until this wave's DMA of stage ks has landed (at most two
+      // younger groups of IA + IB instructions may stay in flight), barrier (every wave's piece has landed AND every wave is done
+      // with stage ks - 1), request stage ks + 3 into the slot stage ks - 1 has just left, multiply stage ks.  One barrier per step.
+      constexpr int NI = IA + IB;
+      const int nk = k_end - k_begin;
+      int ci_i = ci0, tap_i = tapi;                        // the issue cursor runs ahead of the compute cursor
+      auto advance = [&]() { ci_i += BK; if (ci_i >= a.Cin) { ci_i = 0; ++tap_i; tap_setup(tap_i); } };
+      if (nk > 0) {
+        tap_setup(tap_i);
+        issue(0, ci_i);
+#pragma unroll
+        for (int pre = 1; pre < 3; ++pre)
+          if (pre < nk) { advance(); issue(pre, ci_i); }
+      }
+      const int ra_ = (wm * TM) * 32 + (lane & 31);
+      const int rb_ = BM + (wn * TN) * 32 + (lane & 31);
+      const int hlf = lane >> 5;
+      for (int i = 0; i < nk; ++i) {
+        const int young = nk - 1 - i;                      // groups issued after stage i so far: min(2, young)
+        if (young >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");
+        else if (young == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (i + 3 < nk) { advance(); issue((i + 3) & 3, ci_i); }
+        const float* St = smem + (i & 3) * STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = 2 * q + hlf;
+          f32x4 af[TM], bf[TN];
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) {
+            const int r = ra_ + tm * 32;
+            af[tm] = *reinterpret_cast<const f32x4*>(&St[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
+          }
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const int r = rb_ + tn * 32;
+            bf[tn] = *reinterpret_cast<const f32x4*>(&St[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+              for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][r], bf[tn][r], acc[tm][tn], 0, 0, 0);
+        }
+      }
+      __syncthreads();                                     // the stages become the epilogue's staging area
+    } else {
     if (k_begin < k_end) {
       tap_setup(tapi);
       issue(0, ci0);
@@ -624,6 +680,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
               acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][r], bf[tn][r], acc[tm][tn], 0, 0, 0);
       }
       __syncthreads();
+    }
     }
     }
   } else
@@ -1217,8 +1274,9 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr bool GLDS = glds_instance(TM, TN, WM, WN, PRO, SMALLC, X3, POST);
   constexpr bool LOWF = POST == 3;
+  constexpr int GSTAGES = POST == 4 ? 4 : (LOWF ? 1 : 2);
   constexpr int MAIN_FLOATS = X3 ? x3_main_floats(BM, BN, x3_pipelined(PRO, SMALLC, X3))
-                                 : (GLDS ? (LOWF ? 1 : 2) * (BM + BN) * 32 : (BM + BN) * LDK);
+                                 : (GLDS ? GSTAGES * (BM + BN) * 32 : (BM + BN) * LDK);
   constexpr int EPI_FLOATS = (LOWF ? 2 : WM * WN) * 32 * (TN * 32 + 4);
   constexpr int POST_FLOATS = (POST == 1 || POST == 2) ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
   constexpr int F0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
@@ -1301,7 +1359,7 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
   snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%d,%d>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
            a.smallc ? "true" : "false",
            (a.x3 && !a.smallc && bn != 32) ? ((a.x3 == 2 && a.pro == PRO_NONE) ? 2 : 1) : 0,
-           a.post ? (a.post_p ? 2 : 1) : (a.lowfoot && a.bm == 64 && bn == 192 ? 3 : 0));
+           a.post ? (a.post_p ? 2 : 1) : (a.lowfoot && a.bm == 64 && bn == 192 ? 3 : (a.deep && a.bm == 64 && bn == 192 && !a.x3 ? 4 : 0)));
 }
 
 int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream) {
@@ -1335,6 +1393,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
         if (a.x3) return launch_xp<1, 3, 2, 2>(a, stream);
 #ifdef SGA_EXPERIMENTS
         if (a.lowfoot) return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 3>(a, stream);
+        if (a.deep) return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 4>(a, stream);
 #endif
         return launch_inst<1, 3, 2, 2, PRO_NONE, false>(a, stream);
       }

@@ -89,6 +89,9 @@ struct sga_handle {
   // set per concurrently running branch.  fuse_reduce: bit 0 = main chain, bit 1 = hyper branch (SGA_FUSE_REDUCE, laboratory)
   unsigned* sk_tickets[2] = {nullptr, nullptr};
   static constexpr int kTickets = 8192;
+  int deep64 = 0;                  // SGA_DEEP64 (laboratory): bit 0 = main chain, bit 1 = hyper branch: under-filled 64-row launches on the four-stage
+                                   //   instance (conv_mfma.hip POST = 4), split so that one workgroup lands on every CU
+  int deep64_target = 256;         // SGA_DEEP64_TARGET: workgroups such a launch is split into
   int fuse_reduce = 0;             // (off: correct and slower, DESIGN_EXPERIMENTS.md A.10)
   unsigned* ws_sched = nullptr;    // igdn_bwd_ws_kernel's shared tile counter + exit counter (zero between launches)
   int igdn_ws = 0;                 // SGA_IGDN_WS (laboratory build): 0 = igdn2.bwd on gdn_tile_kernel (default), 1 = on the persistent wave-specialised kernel of
@@ -304,7 +307,8 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   // lose with that target and keep 512; profiles/r04_b1_split_targets_by_layer.txt)
   static const int small_tiles = LAB_ENV("SGA_SMALL_TILES") ? atoi(LAB_ENV("SGA_SMALL_TILES")) : 64;      // 0: rule off (experiments)
   if (a.bm != 256 && blocks <= small_tiles) target = 256;
-  if (h->in_hyper && h->side_target > 0) target = h->side_target;   // hyper branch (whichever stream it runs on: the
+  if (a.deep) target = h->deep64_target;
+  else if (h->in_hyper && h->side_target > 0) target = h->side_target;   // hyper branch (whichever stream it runs on: the
                                                                      // split decides the summation order, i.e. result bits)
   const int bn = a.Npad / a.ntiles_n;
   const bool big = blocks > 256 || (blocks == 256 && a.nphase == 1 && !h->split256);
@@ -435,6 +439,15 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
       a.tiles_per_phase = (int)cdiv(rows, 256);
     }
   }
+  a.deep = 0;
+#ifdef SGA_EXPERIMENTS
+  {
+    const long long blocks0 = (long long)a.nphase * a.tiles_per_phase * a.ntiles_n;
+    if ((h->deep64 & (h->in_hyper ? 2 : 1)) && a.bm == 64 && blocks0 <= 256 && !h->x3 && !a.smallc && a.pro == PRO_NONE &&
+        a.Npad / a.ntiles_n == 192)
+      a.deep = 1;
+  }
+#endif
   a.ksplit = pick_ksplit(h, a);
   a.zeros = h->zeros;
   a.prio = (h->cur_part == &h->partB) ? h->side_wave_prio : h->main_wave_prio;
@@ -1839,6 +1852,10 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->fused_mse = !(env && env[0] == '0');
   env = getenv("SGA_NO_SPLITK");
   h->no_splitk = env && env[0] == '1';
+  env = LAB_ENV("SGA_DEEP64");
+  if (env) h->deep64 = atoi(env);
+  env = LAB_ENV("SGA_DEEP64_TARGET");
+  if (env) h->deep64_target = atoi(env);
   env = LAB_ENV("SGA_FUSE_REDUCE");
   if (env) h->fuse_reduce = atoi(env);
   env = LAB_ENV("SGA_IGDN_WS");

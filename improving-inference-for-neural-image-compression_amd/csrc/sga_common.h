@@ -115,6 +115,7 @@ struct ConvArgs {
                            //   wall clock at entry, [1] = max at exit
   int x3w4;                // bf16x3, 256-row tile without post-phase: the 4-wave instance (one wave per SIMD, 128 x 96 per wave)
   int reduce_batch;        // split-K reduce: issue the slab loads 8 at a time (main chain) or one by one
+  int deep;                // 64-row instance in its DEEP form (four LDS stages, counted waits; one workgroup per CU): laboratory, SGA_DEEP64
   int lowfoot;             // 64-row instance in its low-footprint form (one LDS stage, 33 KB): hyper branch, SGA_SIDE_LOWFOOT=1
   int prio;                // wave priority (s_setprio) for the whole launch: experiment, SGA_MAIN_WAVE_PRIO / SGA_SIDE_WAVE_PRIO
   int side;                // the launch belongs to the hyper branch (its split-K reduce: SGA_SIDE_ELEM_PRIO)

@@ -1,0 +1,8 @@
+#!/bin/bash
+# GPU box, round 5: four-stage 64-row convolution instance for the under-filled launches (SGA_DEEP64: 1 main chain, 2 hyper branch)
+cd "$(dirname "$0")/../.."
+OUT=gpurun_out/r05_s14; mkdir -p $OUT
+timeout 600 python scripts/r05/deep64_check.py 2>&1 | grep -v amdgpu.ids > $OUT/check.txt; cat $OUT/check.txt
+timeout 1500 python scripts/ab_iter.py --rounds 2 "LAB=1 SGA_DEEP64=0" "LAB=1 SGA_DEEP64=1" "LAB=1 SGA_DEEP64=2" "LAB=1 SGA_DEEP64=3" > $OUT/ab.txt 2>&1; cat $OUT/ab.txt
+B=1 timeout 900 python scripts/ab_iter.py --rounds 2 "LAB=1 SGA_DEEP64=0" "LAB=1 SGA_DEEP64=1" "LAB=1 SGA_DEEP64=3" "LAB=1 SGA_DEEP64=3 SGA_DEEP64_TARGET=128" > $OUT/ab_b1.txt 2>&1; cat $OUT/ab_b1.txt
+LAB=1 SGA_DEEP64=3 timeout 300 python scripts/profile_layers.py > $OUT/layers_deep.txt 2>&1; grep "gs0\|hs\|igdn0" $OUT/layers_deep.txt
