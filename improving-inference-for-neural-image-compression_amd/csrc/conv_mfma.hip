@@ -83,7 +83,7 @@ constexpr bool glds_instance(int TM, int TN, int WM, int WN, int PRO, bool SMALL
   // 2-wave BN = 96 instance of the hyper branch (same speed alone, but with 56 KB per workgroup it gets in the
   // main chain's way: the iteration measured 1868 against 1827 us)
   return !X3 && !SMALLC && PRO == PRO_NONE &&
-         (((POST <= 1 || POST == 3 || POST == 4) && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2) ||
+         (((POST <= 1 || POST == 3 || POST == 4 || POST == 5) && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2) ||
           (TM == 2 && TN == 4 && WM == 4 && WN == 2));
 }
 
@@ -116,7 +116,7 @@ constexpr int post_qbufs(int BM) { return BM < 128 ? 1 : 2; }
 // X3: 0 = f32 MFMA; 1 = bf16x3 (3 planes, 6 products); 2 = bf16x2 (the two upper planes, 3 products: operands rounded to 16
 // mantissa bits; only the pipelined PRO_NONE loop and the post-phase of such an instance have this form)
 template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, int X3, int POST = 0>
-__global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN >= 8)) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64 + (POST == 5 ? 64 : 0), (X3 && (TN >= 4 || TM >= 4 || WM * WN >= 8)) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int RPP = NT / 8;                 // tile rows covered by one pass of the loaders
@@ -134,6 +134,11 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
   // waits, for launches whose grid cannot put two or three workgroups on every CU (the 16^2 ... 32^2 stages, B = 1): with two
   // stages a step's DMA has one step of one workgroup to land, and a 10-step K chain runs at the L2 latency, not at the MFMA rate
   constexpr bool DEEP = POST == 4;
+  // POST = 5: the 64-row instance with a LOADER WAVE (round 5): a fifth wave issues every LDS-DMA instruction of the workgroup, the
+  // four MFMA waves only read fragments and multiply.  In the plain instance each wave issues 8 DMA instructions per K-step
+  // (60-185 cycles each beside MFMAs, MI355X_MICROARCH.md) in front of its 48 MFMAs (3 072 cycles); only co-resident workgroups
+  // hide that.  Same stages, same fragment reads, same MFMA order: bit-identical to the plain instance.
+  constexpr bool LOADER = POST == 5;
   constexpr int GSTAGES = DEEP ? 4 : (LOWF ? 1 : 2);
   constexpr bool HASPOST = POST == 1 || POST == 2;
   constexpr bool X3P = x3_pipelined(PRO, SMALLC, X3);
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
   constexpr int LDS_FLOATS0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   constexpr int LDS_FLOATS = LDS_FLOATS0 > POST_FLOATS ? LDS_FLOATS0 : POST_FLOATS;
   static_assert(!POST || (((BM == 256 && (BN == 192 || BN == 256) && NT == 512 && TM == 2 && HASPOST) ||
-                           (BM == 64 && BN == 192 && NT == 256 && TM == 1 && (POST == 1 || POST == 3 || POST == 4))) && !SMALLC && PRO == PRO_NONE),
+                           (BM == 64 && BN == 192 && NT == 256 && TM == 1 && (POST == 1 || POST == 3 || POST == 4 || POST == 5))) && !SMALLC && PRO == PRO_NONE),
                 "post-phase instance");
   constexpr int PBX = X3 ? (BN * 12 + NT - 1) / NT : 1;     // 16-byte pieces of the 3-plane weight tile per thread
   constexpr bool PBX_TAIL = X3 && (BN * 12) % NT != 0;       // ... the last round covers part of the threads (8 waves x BN = 192)
@@ -555,6 +560,92 @@ __global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN
       for (int p = 0; p < IB; ++p)
         dma16_to_lds(gb_src[p] + ci, st + lds_b + p * 256);
     };
+    if constexpr (LOADER) {
+      constexpr int IAL = BM / 8, IBL = BN / 8;            // DMA instructions per stage: 8 rows x 8 slots each
+      if (wid == NW) {
+        // ---- the loader wave: all IAL + IBL pieces of every stage ----
+        int l_iy[IAL], l_ix[IAL], l_base[IAL], l_chunk[IAL], lb_chunk[IBL];
+#pragma unroll
+        for (int p = 0; p < IAL; ++p) {
+          const int r = p * 8 + r8;
+          const int m = m0 + r;
+          l_chunk[p] = (slot ^ ((r >> 1) & 7)) * 4;
+          if (m < Mtot) {
+            const int j = m % a.Wg;
+            const int t = m / a.Wg;
+            l_iy[p] = (t % a.Hg) * a.s_in; l_ix[p] = j * a.s_in; l_base[p] = (t / a.Hg) * a.Hin * a.Win;
+          } else {
+            l_iy[p] = -(1 << 20); l_ix[p] = 0; l_base[p] = 0;
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < IBL; ++p) lb_chunk[p] = (slot ^ (((BM + p * 8 + r8) >> 1) & 7)) * 4;
+        const float* la_src[IAL];
+        const float* lb_src[IBL];
+        auto l_tap = [&](int t) {
+          const ConvTap tp = a.taps[ph.tap_begin + t];
+#pragma unroll
+          for (int p = 0; p < IAL; ++p) {
+            const int iy = l_iy[p] + tp.dy, ix = l_ix[p] + tp.dx;
+            const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            la_src[p] = ok ? a.in + ((size_t)(l_base[p] + iy * a.Win + ix) * a.in_cs + a.in_coff + l_chunk[p]) : nullptr;
+          }
+#pragma unroll
+          for (int p = 0; p < IBL; ++p)
+            lb_src[p] = a.w + (((size_t)tp.slab * a.Npad + n0 + p * 8 + r8) * a.Cin + lb_chunk[p]);
+        };
+        auto l_issue = [&](int stage, int ci) {
+          float* st = smem + stage * STAGE;
+#pragma unroll
+          for (int p = 0; p < IAL; ++p) dma16_to_lds(la_src[p] ? la_src[p] + ci : a.zeros, st + p * 256);
+#pragma unroll
+          for (int p = 0; p < IBL; ++p) dma16_to_lds(lb_src[p] + ci, st + BM * 32 + p * 256);
+        };
+        if (k_begin < k_end) { l_tap(tapi); l_issue(0, ci0); }
+        __syncthreads();
+        for (int ks = k_begin; ks < k_end; ++ks) {
+          const int cur = (ks - k_begin) & 1;
+          if (ks + 1 < k_end) {
+            ci0 += BK;
+            if (ci0 >= a.Cin) { ci0 = 0; ++tapi; l_tap(tapi); }
+            l_issue(cur ^ 1, ci0);
+          }
+          __syncthreads();                                 // (vmcnt(0) before the barrier: the next stage has landed)
+        }
+        return;                                            // the epilogue belongs to the four MFMA waves
+      }
+      // ---- the MFMA waves ----
+      __syncthreads();
+      const int ra_ = (wm * TM) * 32 + (lane & 31);
+      const int rb_ = BM + (wn * TN) * 32 + (lane & 31);
+      const int hlf = lane >> 5;
+      for (int ks = k_begin; ks < k_end; ++ks) {
+        const float* St = smem + ((ks - k_begin) & 1) * STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = 2 * q + hlf;
+          f32x4 af[TM], bf[TN];
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) {
+            const int r = ra_ + tm * 32;
+            af[tm] = *reinterpret_cast<const f32x4*>(&St[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
+          }
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const int r = rb_ + tn * 32;
+            bf[tn] = *reinterpret_cast<const f32x4*>(&St[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+              for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][r], bf[tn][r], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+      }
+    } else
     if constexpr (DEEP) {
       // stage ks lives in slot (ks - k_begin) % 4.  Iteration ks: wait until this wave's DMA of stage ks has landed (at most two
       // younger groups of IA + IB instructions may stay in flight), barrier (every wave's piece has landed AND every wave is done
@@ -1297,7 +1388,7 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
     for (int p = 0; p < a.nphase; ++p) grid += a.tiles_per_phase * a.ntiles_n * a.nsplit[p];
   }
   if (grid <= 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC, X3, POST>), dim3(grid), dim3(NT), lds,
+  hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC, X3, POST>), dim3(grid), dim3(NT + (POST == 5 ? 64 : 0)), lds,
                      stream, a);
   return (int)hipGetLastError();
 }
@@ -1359,7 +1450,7 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
   snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%d,%d>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
            a.smallc ? "true" : "false",
            (a.x3 && !a.smallc && bn != 32) ? ((a.x3 == 2 && a.pro == PRO_NONE) ? 2 : 1) : 0,
-           a.post ? (a.post_p ? 2 : 1) : (a.lowfoot && a.bm == 64 && bn == 192 ? 3 : (a.deep && a.bm == 64 && bn == 192 && !a.x3 ? 4 : 0)));
+           a.post ? (a.post_p ? 2 : 1) : (a.lowfoot && a.bm == 64 && bn == 192 ? 3 : (a.deep && a.bm == 64 && bn == 192 && !a.x3 ? 3 + a.deep : 0)));
 }
 
 int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream) {
@@ -1393,7 +1484,8 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
         if (a.x3) return launch_xp<1, 3, 2, 2>(a, stream);
 #ifdef SGA_EXPERIMENTS
         if (a.lowfoot) return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 3>(a, stream);
-        if (a.deep) return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 4>(a, stream);
+        if (a.deep == 1) return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 4>(a, stream);
+        if (a.deep == 2) return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 5>(a, stream);
 #endif
         return launch_inst<1, 3, 2, 2, PRO_NONE, false>(a, stream);
       }

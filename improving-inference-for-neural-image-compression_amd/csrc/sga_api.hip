@@ -92,6 +92,8 @@ struct sga_handle {
   int deep64 = 0;                  // SGA_DEEP64 (laboratory): bit 0 = main chain, bit 1 = hyper branch: under-filled 64-row launches on the four-stage
                                    //   instance (conv_mfma.hip POST = 4), split so that one workgroup lands on every CU
   int deep64_target = 256;         // SGA_DEEP64_TARGET: workgroups such a launch is split into
+  int deep64_kind = 1;             // SGA_DEEP64_KIND: 1 = four-stage instance (POST = 4), 2 = loader-wave instance (POST = 5: every 64-row launch
+                                   //   without a post-phase, default split: bit-identical to the plain instance)
   int fuse_reduce = 0;             // (off: correct and slower, DESIGN_EXPERIMENTS.md A.10)
   unsigned* ws_sched = nullptr;    // igdn_bwd_ws_kernel's shared tile counter + exit counter (zero between launches)
   int igdn_ws = 0;                 // SGA_IGDN_WS (laboratory build): 0 = igdn2.bwd on gdn_tile_kernel (default), 1 = on the persistent wave-specialised kernel of
@@ -307,7 +309,7 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   // lose with that target and keep 512; profiles/r04_b1_split_targets_by_layer.txt)
   static const int small_tiles = LAB_ENV("SGA_SMALL_TILES") ? atoi(LAB_ENV("SGA_SMALL_TILES")) : 64;      // 0: rule off (experiments)
   if (a.bm != 256 && blocks <= small_tiles) target = 256;
-  if (a.deep) target = h->deep64_target;
+  if (a.deep == 1) target = h->deep64_target;
   else if (h->in_hyper && h->side_target > 0) target = h->side_target;   // hyper branch (whichever stream it runs on: the
                                                                      // split decides the summation order, i.e. result bits)
   const int bn = a.Npad / a.ntiles_n;
@@ -443,9 +445,9 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
 #ifdef SGA_EXPERIMENTS
   {
     const long long blocks0 = (long long)a.nphase * a.tiles_per_phase * a.ntiles_n;
-    if ((h->deep64 & (h->in_hyper ? 2 : 1)) && a.bm == 64 && blocks0 <= 256 && !h->x3 && !a.smallc && a.pro == PRO_NONE &&
-        a.Npad / a.ntiles_n == 192)
-      a.deep = 1;
+    if ((h->deep64 & (h->in_hyper ? 2 : 1)) && a.bm == 64 && (blocks0 <= 256 || h->deep64_kind == 2) && !h->x3 && !a.smallc &&
+        a.pro == PRO_NONE && a.Npad / a.ntiles_n == 192)
+      a.deep = h->deep64_kind;
   }
 #endif
   a.ksplit = pick_ksplit(h, a);
@@ -1854,6 +1856,8 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->no_splitk = env && env[0] == '1';
   env = LAB_ENV("SGA_DEEP64");
   if (env) h->deep64 = atoi(env);
+  env = LAB_ENV("SGA_DEEP64_KIND");
+  if (env) h->deep64_kind = atoi(env);
   env = LAB_ENV("SGA_DEEP64_TARGET");
   if (env) h->deep64_target = atoi(env);
   env = LAB_ENV("SGA_FUSE_REDUCE");
