@@ -73,6 +73,11 @@ CFGS = {
                         weights="fitted_c192", inputs="lowpass", seeds=list(range(16))),
     "fitted_c192_b011": dict(C=192, B=2, H=128, W=128, its=2000, lmbda=0.01, x_seed=25, weight_seed=0, scale_bound=0.11,
                              weights="fitted_c192", inputs="lowpass", seeds=list(range(16))),
+    # ... and AT THE BENCHMARKED GEOMETRY (B = 8, 256^2, C = 192) on the fitted model: with trained-like weights the seed-to-seed spread
+    # is a few 1e-4 bpp instead of 1e-2, so eight seeds RESOLVE the north-star tolerance where the synthetic-weight cfg2 set cannot
+    # (round 5; ~2.3 h per seed on one core)
+    "cfg2_fitted": dict(C=192, B=8, H=256, W=256, its=2000, lmbda=0.01, x_seed=27, weight_seed=0, scale_bound=0.0,
+                        weights="fitted_c192", inputs="lowpass", seeds=list(range(8))),
     # CONTROL for the statistical criterion: the small set's inputs and Philox seeds through the float64 oracle.  The
     # float32-vs-float64 ORACLE difference is what "a different rounding of the same arithmetic" does to a 2000-step run;
     # tests/test_oracle.py asserts it has the spread the GPU acceptance test tolerates
