@@ -174,8 +174,15 @@ def _acceptance(gpu_out_dir, golden, precision, tag):
     k = d_bpp.shape[0]
     noisy = k < 16 or bool(cfg.get("weights"))
     rep["per_image_criterion"] = "3.5 standard errors (noisy set)" if noisy else "hard 1e-3 bpp / 0.01 dB"
-    img_tol = np.maximum(TOL_BPP, 3.5 * d_bpp.std(0, ddof=1) / np.sqrt(k)) if noisy else np.full(d_bpp.shape[1], TOL_BPP)
-    img_tol_p = np.maximum(TOL_PSNR, 3.5 * d_psnr.std(0, ddof=1) / np.sqrt(k)) if noisy else np.full(d_psnr.shape[1], TOL_PSNR)
+    # (k < 16: the standard error itself is estimated from few runs, so the multiplier is the Student-t quantile at the two-sided
+    #  tail probability of 3.5 sigma -- 5.9 for k = 8 -- instead of the normal one; sets with >= 16 seeds keep 3.5)
+    nse = 3.5
+    if k < 16:
+        from scipy import stats
+        nse = float(stats.t.ppf(1.0 - stats.norm.sf(3.5), k - 1))
+    rep["per_image_standard_errors"] = nse
+    img_tol = np.maximum(TOL_BPP, nse * d_bpp.std(0, ddof=1) / np.sqrt(k)) if noisy else np.full(d_bpp.shape[1], TOL_BPP)
+    img_tol_p = np.maximum(TOL_PSNR, nse * d_psnr.std(0, ddof=1) / np.sqrt(k)) if noisy else np.full(d_psnr.shape[1], TOL_PSNR)
     rep["per_image_tol_bpp"], rep["per_image_tol_psnr"] = img_tol.tolist(), img_tol_p.tolist()
     assert (np.abs(d_bpp.mean(0)) <= img_tol).all(), rep
     assert (np.abs(d_psnr.mean(0)) <= img_tol_p).all(), rep
