@@ -245,9 +245,11 @@ def test_trace_at_the_benchmarked_geometry(gpu_out_dir):
     codec.close()
 
 
+@pytest.mark.parametrize("golden", ["cfg2trace2000", "cfg2_fitted_trace2000"])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x2"])
-def test_trace_2000_at_the_production_schedule(gpu_out_dir, precision):
-    """(round 5: also in the two bf16-pipe modes, whose per-step error is larger -- same golden trace, the f32 test's bounds, the
+def test_trace_2000_at_the_production_schedule(gpu_out_dir, precision, golden):
+    """(round 5: also on the FITTED C = 192 model -- `cfg2_fitted_trace2000`: the same geometry and schedule at a codec's operating
+    point, 0.35 bpp / 36.6 dB, where 89 % of y_hat end at 0 -- and in the two bf16-pipe modes, whose per-step error is larger -- same golden trace, the f32 test's bounds, the
     first-divergence iterations reported per mode in acceptance_trace2000_cfg2_<mode>.json; VERDICT r4 #3c.)
     cfg 2 under the PRODUCTION schedule (t0 = 700, rate 1e-3: sga.py:193-196), all 2000 iterations, step by step against
     the oracle's committed trace of the same run (`full_run_oracle_cfg2trace2000.json` = seed 0 of the cfg-2 golden set
@@ -260,9 +262,9 @@ def test_trace_2000_at_the_production_schedule(gpu_out_dir, precision):
     3e-3 afterwards (3 sigma of the seed-to-seed spread of the batch-mean bpp at this geometry: sigma_image 7e-3 .. 1.3e-2
     of 4.1 bpp over 8 images), mean PSNR within 0.01 dB throughout, and the end point within the same bounds."""
     from sga_amd.codec import SGACodec
-    path = os.path.join(ROOT, "tests", "golden", "full_run_oracle_cfg2trace2000.json")
+    path = os.path.join(ROOT, "tests", "golden", "full_run_oracle_%s.json" % golden)
     if not os.path.exists(path):
-        pytest.skip("full_run_oracle_cfg2trace2000.json not generated yet (GOLDEN=cfg2trace2000 tests/tools/make_golden_full_run.py)")
+        pytest.skip("full_run_oracle_%s.json not generated yet (GOLDEN=%s tests/tools/make_golden_full_run.py)" % (golden, golden))
     with open(path) as f:
         gold = json.load(f)
     cfg, run = gold["config"], gold["runs"][0]
@@ -288,10 +290,11 @@ def test_trace_2000_at_the_production_schedule(gpu_out_dir, precision):
                end_d_bpp_mean=float(m["est_bpp"].mean() - np.mean(run["est_bpp"])),
                end_d_psnr_mean=float(m["psnr"].mean() - np.mean(run["psnr"])),
                frac_nonzero_y_hat_oracle=run.get("frac_nonzero_y_hat", (1.0 - run["frac_zero_y_hat"]) if "frac_zero_y_hat" in run else None), frac_nonzero_y_hat_hip=float((y_hat != 0).float().mean()))
-    with open(os.path.join(gpu_out_dir, "acceptance_trace2000_cfg2%s.json" % ("" if precision == "f32" else "_" + precision)), "w") as f:
+    with open(os.path.join(gpu_out_dir, "acceptance_trace2000_%s%s.json" % (golden.replace("trace2000", "").rstrip("_"),
+                                                                             "" if precision == "f32" else "_" + precision)), "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps(rep))
     assert (rel[:300, :3] < 1e-4).all(), rep
     assert (rel[:, :3] < 3e-3).all() and (np.abs(got[:, 3] - want[:, 3]) < 0.01).all(), rep
-    assert abs(rep["end_d_bpp_mean"]) < 3e-3 * 4.1 and abs(rep["end_d_psnr_mean"]) < 0.01, rep
+    assert abs(rep["end_d_bpp_mean"]) < 3e-3 * float(np.mean(run["est_bpp"])) and abs(rep["end_d_psnr_mean"]) < 0.01, rep
     codec.close()

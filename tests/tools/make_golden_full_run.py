@@ -78,6 +78,9 @@ CFGS = {
     # (round 5; ~2.3 h per seed on one core)
     "cfg2_fitted": dict(C=192, B=8, H=256, W=256, its=2000, lmbda=0.01, x_seed=27, weight_seed=0, scale_bound=0.0,
                         weights="fitted_c192", inputs="lowpass", seeds=list(range(8))),
+    # seed 0 of "cfg2_fitted" with its per-iteration trace kept: the production schedule step by step at a codec's operating point
+    "cfg2_fitted_trace2000": dict(C=192, B=8, H=256, W=256, its=2000, lmbda=0.01, x_seed=27, weight_seed=0, scale_bound=0.0,
+                                  weights="fitted_c192", inputs="lowpass", trace=True, seeds=[0]),
     # CONTROL for the statistical criterion: the small set's inputs and Philox seeds through the float64 oracle.  The
     # float32-vs-float64 ORACLE difference is what "a different rounding of the same arithmetic" does to a 2000-step run;
     # tests/test_oracle.py asserts it has the spread the GPU acceptance test tolerates
