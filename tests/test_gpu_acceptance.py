@@ -294,7 +294,19 @@ def test_trace_2000_at_the_production_schedule(gpu_out_dir, precision, golden):
                                                                              "" if precision == "f32" else "_" + precision)), "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps(rep))
-    assert (rel[:300, :3] < 1e-4).all(), rep
-    assert (rel[:, :3] < 3e-3).all() and (np.abs(got[:, 3] - want[:, 3]) < 0.01).all(), rep
-    assert abs(rep["end_d_bpp_mean"]) < 3e-3 * float(np.mean(run["est_bpp"])) and abs(rep["end_d_psnr_mean"]) < 0.01, rep
+    if cfg.get("weights"):
+        # The FITTED model: measured (profiles/r05_acceptance_trace2000_cfg2_fitted*.json), the two float32 trajectories separate ten
+        # times EARLIER than on the synthetic weights -- 1e-5 at iteration 15 in all three modes, 1e-4 at 34-56, 1e-3 at ~190 (synthetic:
+        # 345 / never / never): 89 % of the rounded latents are zero here (`frac_zero_y_hat`), the objective is 0.5-0.77 instead of
+        # 72-85, and a last-bit difference flips a floor / ceil draw within tens of iterations.  From then on they are two draws of the
+        # same optimiser: mid-run rd_loss differs by up to 0.9 %, the END agrees to 5e-5 bpp / 0.004 dB (the statistics of
+        # `cfg2_fitted`: sigma 1.5-3.8e-4 bpp).  So: ONE trajectory to 1e-5 over the first 10 iterations (an implementation difference
+        # shows at once) and to 1e-4 over the first 25; a sanity bound afterwards; the north-star tolerance itself at the end.
+        assert (rel[:10, :3] < 1e-5).all() and (rel[:25, :3] < 1e-4).all(), rep
+        assert (rel[:, :3] < 3e-2).all() and (np.abs(got[:, 3] - want[:, 3]) < 0.06).all(), rep
+        assert abs(rep["end_d_bpp_mean"]) < TOL_BPP and abs(rep["end_d_psnr_mean"]) < TOL_PSNR, rep
+    else:
+        assert (rel[:300, :3] < 1e-4).all(), rep
+        assert (rel[:, :3] < 3e-3).all() and (np.abs(got[:, 3] - want[:, 3]) < 0.01).all(), rep
+        assert abs(rep["end_d_bpp_mean"]) < 3e-3 * float(np.mean(run["est_bpp"])) and abs(rep["end_d_psnr_mean"]) < 0.01, rep
     codec.close()
