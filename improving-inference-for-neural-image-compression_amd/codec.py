@@ -418,23 +418,35 @@ class SGACodec:
                                  torch.as_tensor(coder.scale_table, dtype=torch.float64, device=dev).contiguous())
         return self._ec_dev_tabs[1:]
 
-    def _ec_encode_device(self, coder, sym, tab):
-        """sym / tab (int32 device tensors) -> one blocked rANS stream (bytes), encoded by one lane per block."""
+    def _ec_encode_device(self, coder, sym, tab, block=None):
+        """sym / tab (int32 device tensors) -> one blocked rANS stream (bytes), encoded by one lane per block.  block=None: a
+        first pass at ec.BLOCK symbols per block, then the pass that is written at `ec.adapted_block` (the host coder's rule)."""
         from . import entropy_coding as ec
         cdf, lens, offs, _ = self._ec_tables(coder)
         n = sym.numel()
-        nb = -(-n // ec.BLOCK)
-        cap = 16 + 8 * ec.BLOCK
-        slots = torch.empty(nb * cap, dtype=torch.uint8, device=self.device)
-        bb = torch.empty(nb, dtype=torch.int32, device=self.device)
-        s = self._enter()
-        _lib.check(self.lib, None, self.lib.sga_ec_encode(_ptr(sym), _ptr(tab), n, ec.BLOCK, _ptr(cdf), _ptr(lens),
-                                                          _ptr(offs), coder.stride, _ptr(slots), cap, _ptr(bb), s),
-                   "sga_ec_encode")
-        self._exit()
-        bbh = bb.cpu().numpy().astype(np.uint32)
-        if (bbh == 0).any():
-            raise RuntimeError("sga_ec_encode: output slot overflow")
+
+        def one_pass(blk):
+            nb = -(-n // blk)
+            cap = 16 + 8 * blk
+            slots = torch.empty(nb * cap, dtype=torch.uint8, device=self.device)
+            bb = torch.empty(nb, dtype=torch.int32, device=self.device)
+            s = self._enter()
+            _lib.check(self.lib, None, self.lib.sga_ec_encode(_ptr(sym), _ptr(tab), n, blk, _ptr(cdf), _ptr(lens),
+                                                              _ptr(offs), coder.stride, _ptr(slots), cap, _ptr(bb), s),
+                       "sga_ec_encode")
+            self._exit()
+            bbh = bb.cpu().numpy().astype(np.uint32)
+            if (bbh == 0).any():
+                raise RuntimeError("sga_ec_encode: output slot overflow")
+            return nb, cap, slots, bb, bbh
+
+        blk = int(block) if block else ec.BLOCK
+        nb, cap, slots, bb, bbh = one_pass(blk)
+        if not block:
+            blk2 = ec.adapted_block(bbh, blk)
+            if blk2 != blk:
+                blk = blk2
+                nb, cap, slots, bb, bbh = one_pass(blk)
         off = np.concatenate([[0], np.cumsum(bbh[:-1], dtype=np.uint64)]).astype(np.uint64)
         out = torch.empty(int(bbh.sum()), dtype=torch.uint8, device=self.device)
         offd = torch.as_tensor(off.astype(np.int64), device=self.device)
@@ -442,7 +454,7 @@ class SGACodec:
         _lib.check(self.lib, None, self.lib.sga_ec_compact(_ptr(slots), cap, _ptr(bb), _ptr(offd), nb, _ptr(out), s),
                    "sga_ec_compact")
         self._exit()
-        return ec.frame_blocks(bbh, out.cpu().numpy().tobytes())
+        return ec.frame_blocks(bbh, out.cpu().numpy().tobytes(), blk)
 
     def _ec_decode_device(self, coder, data: bytes, tab):
         from . import entropy_coding as ec

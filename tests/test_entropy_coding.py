@@ -59,6 +59,33 @@ def test_y_round_trip_and_size(coder):
     assert coder.ideal_bits_y(yk, mk, sk) < exact * 1.08 + 100
 
 
+def test_block_size_follows_the_rate(coder):
+    """A trained codec's y_hat is ~90 % zeros under sigma ~ 0.1: a 1024-symbol block then holds a handful of bytes and its 8
+    bytes of framing dominate.  The encoder's second pass doubles the block until the mean payload is >= 512 bytes
+    (`ec.adapted_block`); dense latents keep 1024.  Exact round trip either way, the block size travels in the frame."""
+    rng = np.random.RandomState(5)
+    shape = (4, 16, 16, 64)
+    mu = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+    sigma = np.full(shape, 0.1, np.float32)
+    y = np.where(rng.rand(*shape) < 0.02, rng.randint(-3, 4, shape), 0).astype(np.float32)
+    r0, tab = coder._y_symbols(y, mu, sigma)
+    sym = y.astype(np.int32) - r0
+    fixed = coder._run_encode(sym, tab, block=ec.BLOCK)
+    auto = coder.encode_y(y, mu, sigma)
+    bb_f, blk_f, _ = ec.unframe_blocks(fixed)
+    bb_a, blk_a, _ = ec.unframe_blocks(auto)
+    assert blk_f == ec.BLOCK and blk_a > ec.BLOCK and blk_a == ec.adapted_block(bb_f) and bb_a.size < bb_f.size
+    assert np.array_equal(coder.decode_y(auto, mu, sigma), y) and np.array_equal(coder.decode_y(fixed, mu, sigma), y)
+    ideal = coder.ideal_bits_y(y, mu, sigma)
+    assert 8 * len(auto) < ideal * 1.02 + 64 + 64 * (bb_a.size + 1) and len(auto) < 0.9 * len(fixed)
+    # dense latents: the first pass is the stream
+    sig2 = np.full(shape, 8.0, np.float32)
+    y2 = np.rint(mu + sig2 * rng.standard_normal(shape)).astype(np.float32)
+    _, blk2, _ = ec.unframe_blocks(coder.encode_y(y2, mu, sig2))
+    assert blk2 == ec.BLOCK
+    assert ec.adapted_block(np.array([11, 12, 10])) == ec.BLOCK_MAX and ec.adapted_block(np.array([600, 700])) == ec.BLOCK
+
+
 def test_container_and_corruption(coder):
     z = np.rint(np.random.RandomState(2).standard_normal((1, 2, 2, 64)) * 3).astype(np.float32)
     zb = coder.encode_z(z)

@@ -195,6 +195,58 @@ def test_bits_back_rate_at_kodak_size_trained_like_weights(gpu_out_dir):
     codec.close()
 
 
+def test_real_bytes_at_the_trained_like_operating_point_c192(gpu_out_dir):
+    """What the reference's README quotes is a FILE size (mbt2018.py:211-222 writes the packed strings) next to a PSNR of the decoded
+    image (mbt2018.py:283-288), at 0.1-1.2 bpp.  So: the fitted C = 192 model (0.39 bpp / 33.5 dB one-shot, 87 % of y_hat at 0, 78 % of
+    the predicted scales under the coder's lower bound 0.11), four 256 x 256 low-pass images, sigma bounded as the coder's tables
+    are.  (i) the one-shot encode (the encoder's output rounded: the run's starting point) and a 2000-iteration SGA run are both
+    entropy-coded on the device: byte-equal to the host coder, decoded exactly; (ii) the FILE is 0-5 % larger than the model's
+    estimate (measured 2.9 / 3.3 %: ~2.3 % quantisation of (sigma, frac mu) to 64 x 8 tables, ~1 % container and block framing --
+    15 % before the block size followed the rate, entropy_coding.adapted_block); (iii) the decoder's reconstruction from the DECODED
+    latents has the PSNR the run reported; (iv) the paper's claim with real bytes: at this lambda SGA buys > 1 dB at the same file
+    size (within 3 %), i.e. a lower lambda * mse + bpp with the file's own rate."""
+    import json, os
+    from sga_amd.codec import SGACodec, metrics_to_dict
+    C, B, H, W = 192, 4, 256, 256
+    w = sga_amd.load_weights_npz(os.path.join(os.path.dirname(__file__), "golden", "fitted_weights_c192.npz"))
+    codec = SGACodec(w, C, B, H, W)
+    codec.set_scale_bound(0.11)
+    x = sga_amd.make_lowpass_images(B, H, W, seed=77)
+    xt = torch.as_tensor(x, device="cuda")
+    rep = dict(test="real_bytes_fitted_c192")
+    lmbda = 0.01                      # what the weights were fitted at
+    sizes, psnrs, cost = {}, {}, {}
+    for name in ("one_shot", "sga"):
+        if name == "one_shot":      # sga.py's starting point coded as it is: the encoder's output rounded (integer latents, as this coder and
+            y0, z0 = codec.encode(x)      # sga.py:166 have them; mbt2018.py's mean-centred rounding is `base_compress`, estimate only)
+            y_hat, z_hat = torch.round(y0), torch.round(z0)
+            met = codec.evaluate(x, y_hat, z_hat)
+        else:
+            y_hat, z_hat, met, _ = codec.run(x, lmbda, its=2000, seed=5)
+        m = metrics_to_dict(met)
+        dev = codec.compress_latents((B, H, W), y_hat, z_hat, on_device=True)
+        assert dev == codec.compress_latents((B, H, W), y_hat, z_hat, on_device=False)
+        xs, y2, z2 = codec.decompress_latents(dev, on_device=True)
+        assert tuple(xs) == (B, H, W) and torch.equal(y2, y_hat) and torch.equal(z2, z_hat)
+        x_hat = codec.reconstruct(y2, H, W)
+        mse = ((torch.round(x_hat * 255) - xt * 255) ** 2).mean(dim=(1, 2, 3))                   # sga.py:167-174: the output on 8-bit pixels
+        psnr = (20 * np.log10(255.0) - 10 * torch.log10(mse)).cpu().numpy()
+        actual_bpp = 8.0 * len(dev) / (B * H * W)
+        est_bpp = float(m["est_bpp"].mean())
+        rep[name] = dict(bytes=len(dev), actual_bpp=actual_bpp, est_bpp=est_bpp, psnr_decoded=float(psnr.mean()), psnr_reported=float(m["psnr"].mean()),
+                         frac_zero_y_hat=float((y_hat == 0).float().mean()))
+        sizes[name], psnrs[name] = actual_bpp, float(psnr.mean())
+        cost[name] = actual_bpp + lmbda * float(mse.mean())              # sga.py:150-151 with the FILE's rate
+        assert np.abs(psnr - m["psnr"]).max() < 2e-3, rep
+        assert 0 < actual_bpp / est_bpp - 1 < 0.05, rep
+    rep["rd_cost"] = cost
+    with open(os.path.join(gpu_out_dir, "parity_entropy.jsonl"), "a") as f:
+        f.write(json.dumps(rep) + "\n")
+    assert 0.1 < sizes["one_shot"] < 1.2 and rep["one_shot"]["frac_zero_y_hat"] > 0.8, rep      # a codec's regime (results/kodak/sga-psnr.csv)
+    assert cost["sga"] < cost["one_shot"] - 0.02 and psnrs["sga"] > psnrs["one_shot"] + 1.0 and sizes["sga"] < 1.03 * sizes["one_shot"], rep
+    codec.close()
+
+
 def test_rans_oracle_decodes_the_device_stream():
     """the device coder (csrc/rans.hip) checked by something that is not the product -- oracle/rans_ref.py
     (the published rANS recurrences in Python integers) decodes the stream the DEVICE wrote for the (y_hat, mu, sigma) of a
