@@ -18,7 +18,7 @@ LAB_LIB_PATH = os.path.join(_PKG_DIR, "libsga_hip_lab.so")
 PRODUCT_ENV_KNOBS = ("SGA_PRECISION", "SGA_NO_GRAPH", "SGA_NO_OVERLAP", "SGA_NO_SPLITK", "SGA_FORK_NAME", "SGA_FORK_VERBOSE",
                      "SGA_PROFILE_BY_LAYER", "SGA_GRAPH_DROP", "SGA_X3_FORK", "SGA_X3_VARIANTS")
 
-SGA_ABI_VERSION = 4
+SGA_ABI_VERSION = 5
 
 STATUS = {
     0: "SGA_OK", -1: "SGA_ERR_BAD_ARG", -2: "SGA_ERR_BAD_SHAPE", -3: "SGA_ERR_UNSUPPORTED",
@@ -116,6 +116,8 @@ SYMBOLS["sga_debug_counter"] = (_I, [_P, _I, C.POINTER(C.c_longlong)])
 
 SYMBOLS["sga_ec_y_symbols"] = (_I, [_P, _P, _P, _I64, _P, _I, _I, _I, _P, _P, _P, _P, _P])
 SYMBOLS["sga_ec_z_symbols"] = (_I, [_P, _I64, _I, _P, _P, _P, _P])
+SYMBOLS["sga_ec_y_symbols_centred"] = (_I, [_P, _P, _P, _I64, _P, _I, _I, _P, _P, _P, _P])
+SYMBOLS["sga_ec_z_symbols_centred"] = (_I, [_P, _P, _I64, _I, _P, _P, _P, _P])
 SYMBOLS["sga_ec_encode"] = (_I, [_P, _P, _I64, _I, _P, _P, _P, _I, _P, _I, _P, _P])
 SYMBOLS["sga_ec_compact"] = (_I, [_P, _I, _P, _P, _I, _P, _P])
 SYMBOLS["sga_ec_decode"] = (_I, [_P, _P, _P, _I, _P, _I64, _I, _P, _P, _P, _I, _P, _P, _P])

@@ -390,11 +390,21 @@ class SGACodec:
         t = t[:, :yh, :yw, :]
         return t[..., :self.C].contiguous(), torch.exp(t[..., self.C:]).contiguous()
 
-    def _entropy_coder(self, weights=None, device_tables=True):
+    def _entropy_coder(self, weights=None, device_tables=True, centred=False, medians=None):
         """The coder's quantised CDF tables come from the SAME device kernels that evaluate the entropy
         models in the SGA step (factorized mass, box-convolved Gaussian), so that what is coded is the
-        model whose rate was optimised; device_tables=False builds them with numpy instead."""
-        if getattr(self, "_ec", None) is None or getattr(self, "_ec_dev", None) != device_tables:
+        model whose rate was optimised; device_tables=False builds them with numpy instead.  centred: the tables of
+        mbt2018.py compress (entropy_coding.EntropyCoder: zero-offset tables for y, z tables on the grid median + k); medians
+        default to the weights' `eb.medians` (else 0).  One coder per (device_tables, centred, medians) is kept."""
+        if centred:
+            med = medians if medians is not None else self.medians
+            med = np.zeros(self.C, np.float32) if med is None else np.ascontiguousarray(
+                med.detach().cpu().numpy() if torch.is_tensor(med) else med, np.float32).reshape(self.C)
+        else:
+            med = None
+        key = (bool(device_tables), bool(centred), None if med is None else med.tobytes())
+        cache = self.__dict__.setdefault("_ec_cache", {})
+        if key not in cache:
             from .entropy_coding import EntropyCoder
             dm = None
             if device_tables:
@@ -402,9 +412,9 @@ class SGACodec:
                       # a FIXED bound (the scale table's own minimum), whatever the handle's mutable sigma bound is at the
                       # moment: an encoder and a decoder must build identical tables
                       lambda y, mu, sr: self.gaussian_likelihood(y, mu, sr, scale_bound=_lib.SCALE_BOUND_BUILT)[0].cpu().numpy())
-            self._ec = EntropyCoder(weights if weights is not None else self._weights_for_ec, device_models=dm)
-            self._ec_dev = device_tables
-        return self._ec
+            cache[key] = EntropyCoder(weights if weights is not None else self._weights_for_ec, device_models=dm,
+                                      centred=centred, medians=med)
+        return cache[key]
 
     # ---- the coder itself on the device (csrc/rans.hip) ---------------------------------------------------------
     def _ec_tables(self, coder):
@@ -478,7 +488,7 @@ class SGACodec:
         return sym
 
     def _ec_symbols_device(self, coder, y_hat, mu, sigma, z_hat):
-        """(sym, tab[, r0]) of y (y_hat may be None: decoder) and of z (z_hat may be None) on the device."""
+        """(sym, tab[, r0]) of y (y_hat may be None: decoder) on the device; a centred coder has no r0."""
         from . import entropy_coding as ec
         _, _, _, scales = self._ec_tables(coder)
         i32 = lambda n: torch.empty(n, dtype=torch.int32, device=self.device)
@@ -487,36 +497,55 @@ class SGACodec:
         s = self._enter()
         if mu is not None:
             n = mu.numel()
-            out["y_sym"], out["y_tab"], out["r0"] = (i32(n) if y_hat is not None else None), i32(n), i32(n)
-            _lib.check(self.lib, None,
-                       self.lib.sga_ec_y_symbols(_ptr(y_hat), _ptr(mu), _ptr(sigma), n, _ptr(scales), ec.SCALES_LEVELS,
-                                                 ec.MEAN_BINS, coder.y_tab0, _ptr(out["y_sym"]), _ptr(out["y_tab"]),
-                                                 _ptr(out["r0"]), _ptr(bad), s), "sga_ec_y_symbols")
+            out["y_sym"], out["y_tab"] = (i32(n) if y_hat is not None else None), i32(n)
+            if coder.centred:
+                _lib.check(self.lib, None,
+                           self.lib.sga_ec_y_symbols_centred(_ptr(y_hat), _ptr(mu), _ptr(sigma), n, _ptr(scales), ec.SCALES_LEVELS,
+                                                             coder.y_tab0, _ptr(out["y_sym"]), _ptr(out["y_tab"]), _ptr(bad), s),
+                           "sga_ec_y_symbols_centred")
+            else:
+                out["r0"] = i32(n)
+                _lib.check(self.lib, None,
+                           self.lib.sga_ec_y_symbols(_ptr(y_hat), _ptr(mu), _ptr(sigma), n, _ptr(scales), ec.SCALES_LEVELS,
+                                                     ec.MEAN_BINS, coder.y_tab0, _ptr(out["y_sym"]), _ptr(out["y_tab"]),
+                                                     _ptr(out["r0"]), _ptr(bad), s), "sga_ec_y_symbols")
         self._exit()
         out["bad"] = bad
         return out
 
-    def compress_latents(self, x_shape, y_hat, z_hat, device_tables=True, on_device=True) -> bytes:
+    def _ec_z_symbols_device(self, coder, z_hat, nz, bad=None):
+        """(sym, tab) of z on the device (z_hat None: the decoder's table indices only)."""
+        z_sym = torch.empty(nz, dtype=torch.int32, device=self.device) if z_hat is not None else None
+        z_tab = torch.empty(nz, dtype=torch.int32, device=self.device)
+        s = self._enter()
+        if coder.centred:
+            med = self._t(coder.medians, (self.C,))
+            _lib.check(self.lib, None, self.lib.sga_ec_z_symbols_centred(_ptr(z_hat), _ptr(med), nz, self.C, _ptr(z_sym), _ptr(z_tab),
+                                                                         _ptr(bad), s), "sga_ec_z_symbols_centred")
+        else:
+            _lib.check(self.lib, None, self.lib.sga_ec_z_symbols(_ptr(z_hat), nz, self.C, _ptr(z_sym), _ptr(z_tab), _ptr(bad), s),
+                       "sga_ec_z_symbols")
+        self._exit()
+        return z_sym, z_tab
+
+    def compress_latents(self, x_shape, y_hat, z_hat, device_tables=True, on_device=True, centred=False, medians=None) -> bytes:
         """Entropy-code (y_hat, z_hat) of a batch into one byte string (cf. tfc.PackedTensors).  The stream records
         how its tables were built and their CRC32; device_tables=False gives the float64 host tables, which do
         not depend on the GPU's math library (the interchange mode).  on_device: (mu, sigma) -> table indices -> rANS
-        bytes by the HIP kernels of csrc/rans.hip (one lane per 1024-symbol block); False: the same bytes from the host
-        coder (csrc_cpu/rans.c)."""
+        bytes by the HIP kernels of csrc/rans.hip (one lane per block); False: the same bytes from the host
+        coder (csrc_cpu/rans.c).  centred=False: integer latents, what an SGA run ends with (sga.py:240-241); centred=True:
+        the mean- / median-centred latents of `base_compress` = mbt2018.py compress (mbt2018.py:69,80,211-222), `medians`
+        as passed to it (default: the weights' `eb.medians`, else 0)."""
         from . import entropy_coding as ec
-        coder = self._entropy_coder(device_tables=device_tables)
+        coder = self._entropy_coder(device_tables=device_tables, centred=centred, medians=medians)
         y_hat, z_hat = self._t(y_hat), self._t(z_hat)
         mu, sigma = self.hyper_synthesis(z_hat, y_hat.shape[1], y_hat.shape[2])
         if on_device:
             ys = self._ec_symbols_device(coder, y_hat, mu, sigma, None)
-            nz = z_hat.numel()
-            z_sym = torch.empty(nz, dtype=torch.int32, device=self.device)
-            z_tab = torch.empty(nz, dtype=torch.int32, device=self.device)
-            s = self._enter()
-            _lib.check(self.lib, None, self.lib.sga_ec_z_symbols(_ptr(z_hat), nz, self.C, _ptr(z_sym), _ptr(z_tab),
-                                                                 _ptr(ys["bad"]), s), "sga_ec_z_symbols")
-            self._exit()
+            z_sym, z_tab = self._ec_z_symbols_device(coder, z_hat, z_hat.numel(), ys["bad"])
             if int(ys["bad"].item()):
-                raise ValueError("y_hat / z_hat must hold integers; centred latents are not supported by this coder")
+                raise ValueError("y_hat / z_hat are not their centres + integers (coder centred: mu / medians)" if centred else
+                                 "y_hat / z_hat must hold integers; centred latents need compress_latents(..., centred=True)")
             zb = self._ec_encode_device(coder, z_sym, z_tab)
             yb = self._ec_encode_device(coder, ys["y_sym"], ys["y_tab"])
             return ec.pack(tuple(x_shape), tuple(y_hat.shape), tuple(z_hat.shape), zb, yb, coder.table_mode,
@@ -526,26 +555,29 @@ class SGACodec:
         return ec.pack(tuple(x_shape), tuple(y_hat.shape), tuple(z_hat.shape), zb, yb, coder.table_mode,
                        coder.table_crc())
 
-    def decompress_latents(self, blob: bytes, on_device=True):
-        """-> (x_shape, y_hat, z_hat): z first, then (mu, sigma) = h_s(z_hat), then y."""
+    def decompress_latents(self, blob: bytes, on_device=True, medians=None):
+        """-> (x_shape, y_hat, z_hat): z first, then (mu, sigma) = h_s(z_hat), then y.  The stream's mode byte says how its
+        tables were built and whether it holds centred latents (then `medians` as at the encoder)."""
         from . import entropy_coding as ec
         x_shape, y_shape, z_shape, zb, yb, mode, crc = ec.unpack(blob, with_tables=True)
-        coder = self._entropy_coder(device_tables=bool(mode))
+        coder = self._entropy_coder(device_tables=bool(mode & 1), centred=bool(mode & 2), medians=medians)
         if coder.table_crc() != crc:
             raise ValueError("SGAC stream was coded with different CDF tables (mode %d, crc %08x; this decoder builds "
-                             "%08x): other weights, or device-built tables from another GPU / ROCm build -- encode "
+                             "%08x): other weights or medians, or device-built tables from another GPU / ROCm build -- encode "
                              "with device_tables=False for streams that must travel" % (mode, crc, coder.table_crc()))
         if on_device:
             nz = int(np.prod(z_shape))
-            z_tab = torch.empty(nz, dtype=torch.int32, device=self.device)
-            s = self._enter()
-            _lib.check(self.lib, None, self.lib.sga_ec_z_symbols(None, nz, self.C, None, _ptr(z_tab), None, s),
-                       "sga_ec_z_symbols")
-            self._exit()
+            _, z_tab = self._ec_z_symbols_device(coder, None, nz)
             z_hat = self._ec_decode_device(coder, zb, z_tab).to(torch.float32).reshape(*z_shape)
+            if coder.centred:
+                z_hat = z_hat + self._t(coder.medians, (self.C,))      # float32 add: the operation that made z_hat (mbt2018.py:69)
             mu, sigma = self.hyper_synthesis(z_hat, y_shape[1], y_shape[2])
             ys = self._ec_symbols_device(coder, None, mu, sigma, None)
-            y_hat = (self._ec_decode_device(coder, yb, ys["y_tab"]) + ys["r0"]).to(torch.float32).reshape(*y_shape)
+            sym = self._ec_decode_device(coder, yb, ys["y_tab"])
+            if coder.centred:
+                y_hat = sym.to(torch.float32).reshape(*y_shape) + mu      # round(y - mu) + mu (mbt2018.py:80)
+            else:
+                y_hat = (sym + ys["r0"]).to(torch.float32).reshape(*y_shape)
             return x_shape, y_hat, z_hat
         z_hat = self._t(coder.decode_z(zb, z_shape))
         mu, sigma = self.hyper_synthesis(z_hat, y_shape[1], y_shape[2])

@@ -50,6 +50,42 @@ __global__ void k_y_symbols(const float* __restrict__ y, const float* __restrict
   }
 }
 
+// The same for MEAN-CENTRED latents (mbt2018.py:80 through tfc's conditional bottleneck: y_hat = round(y - mu) + mu): the symbol
+// is round(y_hat - mu), coded under the zero-offset table of its scale level (one table per level: tab0 + level).  `bad` counts
+// elements whose y_hat - mu is not an integer to 1e-3 (float32 noise of the + mu is ~1e-6 at |y| < 100).
+__global__ void k_y_symbols_centred(const float* __restrict__ y, const float* __restrict__ mu, const float* __restrict__ sigma,
+                                    int64_t n, const double* __restrict__ scales, int levels, int tab0, int* __restrict__ sym,
+                                    int* __restrict__ tab, int* __restrict__ bad) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double sg = (double)sigma[i];
+    sg = sg > scales[0] ? sg : scales[0];
+    int lo = 0, hi = levels;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (scales[mid] < sg) lo = mid + 1; else hi = mid; }
+    tab[i] = tab0 + (lo > levels - 1 ? levels - 1 : lo);
+    if (y) {
+      const float d = y[i] - mu[i];
+      const float r = rintf(d);
+      if (fabsf(d - r) > 1e-3f && bad) atomicAdd(bad, 1);
+      sym[i] = (int)r;
+    }
+  }
+}
+
+// ... and z_hat = round(z - median_c) + median_c (mbt2018.py:69 through tfc's EntropyBottleneck): symbol round(z_hat - median_c)
+__global__ void k_z_symbols_centred(const float* __restrict__ z, const float* __restrict__ med, int64_t n, int C,
+                                    int* __restrict__ sym, int* __restrict__ tab, int* __restrict__ bad) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    tab[i] = c;
+    if (z) {
+      const float d = z[i] - med[c];
+      const float r = rintf(d);
+      if (fabsf(d - r) > 1e-3f && bad) atomicAdd(bad, 1);
+      sym[i] = (int)r;
+    }
+  }
+}
+
 // z: integer latent [.., C] with one table per channel
 __global__ void k_z_symbols(const float* __restrict__ z, int64_t n, int C, int* __restrict__ sym, int* __restrict__ tab,
                             int* __restrict__ bad) {
@@ -176,6 +212,22 @@ int sga_ec_z_symbols(const float* z_hat, int64_t n, int num_filters, int32_t* sy
                      void* stream) {
   if (!tab || n <= 0 || num_filters <= 0 || (z_hat && !sym)) return SGA_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_z_symbols, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z_hat, n, num_filters, sym, tab, bad);
+  return hipGetLastError() == hipSuccess ? SGA_OK : SGA_ERR_HIP;
+}
+
+int sga_ec_y_symbols_centred(const float* y_hat, const float* mu, const float* sigma, int64_t n, const double* scale_table,
+                             int levels, int y_tab0, int32_t* sym, int32_t* tab, int32_t* bad, void* stream) {
+  if (!sigma || !scale_table || !tab || n <= 0 || levels <= 0 || (y_hat && (!sym || !mu))) return SGA_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_y_symbols_centred, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y_hat, mu, sigma, n,
+                     scale_table, levels, y_tab0, sym, tab, bad);
+  return hipGetLastError() == hipSuccess ? SGA_OK : SGA_ERR_HIP;
+}
+
+int sga_ec_z_symbols_centred(const float* z_hat, const float* medians, int64_t n, int num_filters, int32_t* sym, int32_t* tab,
+                             int32_t* bad, void* stream) {
+  if (!tab || n <= 0 || num_filters <= 0 || (z_hat && (!sym || !medians))) return SGA_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_z_symbols_centred, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z_hat, medians, n,
+                     num_filters, sym, tab, bad);
   return hipGetLastError() == hipSuccess ? SGA_OK : SGA_ERR_HIP;
 }
 

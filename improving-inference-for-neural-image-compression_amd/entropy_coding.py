@@ -111,8 +111,9 @@ def factorized_mass(w: dict, ks: np.ndarray, half: float = 0.5) -> np.ndarray:
     integer bins of z_hat, smaller: the fine grid of bits_back.py)."""
     Cn = w["eb.m0"].shape[0]
 
-    def logits(v):                       # v [K] -> [K, C]
-        t = np.broadcast_to(v[None, None, :], (Cn, 1, v.size)).astype(np.float64)
+    def logits(v):                       # v [K] (one grid for every channel) or [K, C] -> [K, C]
+        v = np.asarray(v, np.float64)
+        t = (np.broadcast_to(v[None, None, :], (Cn, 1, v.size)) if v.ndim == 1 else v.T[:, None, :]).astype(np.float64)
         for k in range(4):
             t = np.matmul(w[f"eb.m{k}"].astype(np.float64), t) + w[f"eb.b{k}"].astype(np.float64)
             if k < 3:
@@ -154,22 +155,34 @@ def quantise_pmf(pmf: np.ndarray) -> np.ndarray:
 
 
 class EntropyCoder:
-    def __init__(self, weights: dict, z_max_abs: int = 96, tail: float = 2.0 ** -14, device_models=None):
-        """device_models: optional pair (mass_fn, box_fn) evaluating the two entropy models with the
+    def __init__(self, weights: dict, z_max_abs: int = 96, tail: float = 2.0 ** -14, device_models=None, centred: bool = False,
+                 medians=None):
+        """centred=False: INTEGER latents (SGA's y_hat = round(y), sga.py:240-241): y symbol = y_hat - rint(mu) under the table
+        of (scale level, bin of mu - rint(mu)); z symbol = z_hat under its channel's table on the integer grid.
+        centred=True: what mbt2018.py compress codes (mbt2018.py:69,80): y_hat = round(y - mu) + mu, symbol round(y_hat - mu) under
+        the ZERO-offset table of its scale level (one per level); z_hat = round(z - median_c) + median_c, symbol round(z_hat -
+        median_c) under the channel's table on the grid median_c + k (`medians` [C], default weights["eb.medians"] or 0).
+        device_models: optional pair (mass_fn, box_fn) evaluating the two entropy models with the
         HIP kernels of the SGA step instead of numpy -- `mass_fn(v [K, C]) -> p [K, C]` (factorized
         mass, sga_op_factorized_likelihood) and `box_fn(y, mu, sigma_raw) -> p` (box-convolved
         Gaussian, sga_op_gaussian_likelihood); see SGACodec._entropy_coder(device_tables=True).
         Encoder and decoder must build their tables the same way."""
         self.C = weights["eb.m0"].shape[0]
+        self.centred = bool(centred)
+        self.mean_bins = 1 if self.centred else MEAN_BINS
+        if medians is None:
+            medians = weights.get("eb.medians")
+        self.medians = (np.zeros(self.C, np.float32) if medians is None or not self.centred
+                        else np.ascontiguousarray(medians, np.float32).reshape(self.C))
         self.scale_table = np.exp(np.linspace(math.log(SCALES_MIN), math.log(SCALES_MAX), SCALES_LEVELS))
         tables, lens, offs = [], [], []
-        # ---- z: one table per channel -------------------------------------------------------
+        # ---- z: one table per channel (on the grid median_c + k when centred) ----------------
         ks = np.arange(-z_max_abs, z_max_abs + 1, dtype=np.float64)
+        grid = ks[:, None] + self.medians[None, :].astype(np.float64)            # [K, C]
         if device_models is not None:
-            grid = np.broadcast_to(ks[:, None], (ks.size, self.C)).astype(np.float32)
-            mass = np.asarray(device_models[0](grid), np.float64)
+            mass = np.asarray(device_models[0](np.ascontiguousarray(grid, np.float32)), np.float64)
         else:
-            mass = factorized_mass(weights, ks)                # [K, C]
+            mass = factorized_mass(weights, grid if self.centred else ks)      # [K, C]
         for c in range(self.C):
             m = mass[:, c]
             keep = np.nonzero(m >= tail / 8)[0]
@@ -183,8 +196,8 @@ class EntropyCoder:
         specs = []                                               # (R, f, s) of every y table, in table order
         for s in self.scale_table:
             R = int(math.ceil(6.0 * s + 1.0))                    # +-6 sigma, rest escapes
-            for j in range(MEAN_BINS):
-                specs.append((R, (j + 0.5) / MEAN_BINS - 0.5, s))
+            for j in range(self.mean_bins):
+                specs.append((R, 0.0 if self.centred else (j + 0.5) / MEAN_BINS - 0.5, s))
         dev = None
         if device_models is not None:                            # all tables' grids in ONE device call
             ys = np.concatenate([np.arange(-R, R + 1, dtype=np.float32) for R, _, _ in specs])
@@ -209,7 +222,7 @@ class EntropyCoder:
             self.cdf[i, t.size:] = TOTAL
         self.lens = np.asarray(lens, np.int32)
         self.offs = np.asarray(offs, np.int32)
-        self.table_mode = 1 if device_models is not None else 0
+        self.table_mode = (1 if device_models is not None else 0) | (2 if self.centred else 0)      # the container's mode byte
         self._crc = None
 
     def table_crc(self) -> int:
@@ -220,8 +233,24 @@ class EntropyCoder:
         return self._crc
 
     # ---- symbol/table preparation ---------------------------------------------------------------
+    def _levels(self, sigma):
+        sg = np.maximum(np.asarray(sigma, np.float64), SCALES_MIN)
+        return np.clip(np.searchsorted(self.scale_table, sg, side="left"), 0, SCALES_LEVELS - 1).astype(np.int32)
+
+    @staticmethod
+    def _centred_symbols(v, centre, what):
+        """round(v - centre) in float32 (the arithmetic that made v), refusing anything that is not an integer to 1e-3"""
+        d = np.asarray(v, np.float32) - np.asarray(centre, np.float32)
+        r = np.rint(d)
+        if d.size and float(np.abs(d - r).max()) > 1e-3:
+            raise ValueError(f"{what} is not its centre + an integer (max deviation {float(np.abs(d - r).max()):.3g}): "
+                             "a centred coder codes round(v - centre)")
+        return r.astype(np.int32)
+
     def _y_symbols(self, y_hat, mu, sigma):
         mu = np.asarray(mu, np.float32)
+        if self.centred:
+            return np.zeros(mu.shape, np.int32), (self.y_tab0 + self._levels(sigma)).astype(np.int32)
         r0 = np.rint(mu)
         frac = (mu - r0).astype(np.float64)
         jbin = np.clip(np.floor((frac + 0.5) * MEAN_BINS), 0, MEAN_BINS - 1).astype(np.int32)
@@ -288,26 +317,36 @@ class EntropyCoder:
         return r
 
     def encode_z(self, z_hat) -> bytes:
-        z = self._integers(z_hat, "z_hat").astype(np.int32)
+        if self.centred:
+            z = self._centred_symbols(z_hat, self.medians, "z_hat")
+        else:
+            z = self._integers(z_hat, "z_hat").astype(np.int32)
         tab = np.broadcast_to(np.arange(self.C, dtype=np.int32), z.shape)
         return self._run_encode(z, tab)
 
     def decode_z(self, data: bytes, shape) -> np.ndarray:
         tab = np.broadcast_to(np.arange(self.C, dtype=np.int32), shape)
-        return self._run_decode(data, tab).reshape(shape).astype(np.float32)
+        z = self._run_decode(data, tab).reshape(shape).astype(np.float32)
+        return z + self.medians if self.centred else z      # float32 add: the operation that made z_hat (mbt2018.py:69)
 
     def encode_y(self, y_hat, mu, sigma) -> bytes:
         r0, tab = self._y_symbols(y_hat, mu, sigma)
+        if self.centred:
+            return self._run_encode(self._centred_symbols(y_hat, mu, "y_hat"), tab)
         return self._run_encode(self._integers(y_hat, "y_hat").astype(np.int32) - r0, tab)
 
     def decode_y(self, data: bytes, mu, sigma) -> np.ndarray:
         r0, tab = self._y_symbols(None, mu, sigma)
-        return (self._run_decode(data, tab).reshape(r0.shape) + r0).astype(np.float32)
+        sym = self._run_decode(data, tab).reshape(r0.shape)
+        if self.centred:
+            return sym.astype(np.float32) + np.asarray(mu, np.float32)      # round(y - mu) + mu in float32 (mbt2018.py:80)
+        return (sym + r0).astype(np.float32)
 
     def ideal_bits_y(self, y_hat, mu, sigma) -> float:
         """-sum log2 of the QUANTISED model probabilities actually used (for tests)."""
         r0, tab = self._y_symbols(y_hat, mu, sigma)
-        idx = (np.rint(np.asarray(y_hat)).astype(np.int64) - r0 - self.offs[tab]).reshape(-1)
+        sym = self._centred_symbols(y_hat, mu, "y_hat").astype(np.int64) if self.centred else np.rint(np.asarray(y_hat)).astype(np.int64) - r0
+        idx = (sym - self.offs[tab]).reshape(-1)
         tab = tab.reshape(-1)
         ln = self.lens[tab]
         esc = (idx < 0) | (idx >= ln - 1)
@@ -321,7 +360,8 @@ FORMAT_VERSION = 2      # 1 (round 2, magic only) had no table fingerprint
 
 def pack(x_shape, y_shape, z_shape, z_bytes: bytes, y_bytes: bytes, table_mode: int = 0, table_crc: int = 0) -> bytes:
     """Container (cf. tfc.PackedTensors, mbt2018.py:211-214): magic, format version, how the coder's CDF tables were
-    built (0 = host float64 numpy, 1 = device float32 kernels) and their CRC32, shapes, two length-prefixed streams.
+    built (bit 0: 0 = host float64 numpy, 1 = device float32 kernels; bit 1: centred latents, mbt2018.py compress) and their
+    CRC32, shapes, two length-prefixed streams.
     A range coder needs bit-identical tables on both sides: the decoder refuses a stream whose fingerprint is not its own."""
     head = MAGIC + struct.pack("<BBHI", FORMAT_VERSION, table_mode, 0, table_crc & 0xFFFFFFFF)
     head += struct.pack("<3I4I4I", *x_shape, *y_shape, *z_shape)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGA_ABI_VERSION 4
+#define SGA_ABI_VERSION 5
 
 typedef enum sga_status {
   SGA_OK = 0,
@@ -307,6 +307,10 @@ int sga_op_rate_terms(sga_handle* h, const float* y_tilde, const float* z_tilde,
  *   sga_ec_y_symbols : sym = y_hat - rint(mu), tab = y_tab0 + level(sigma) * mean_bins + bin(mu - rint(mu)); r0 = rint(mu)
  *                      (optional); y_hat = NULL: tab / r0 only (decoder).  bad (optional) counts non-integer y_hat.
  *   sga_ec_z_symbols : sym = z_hat, tab = channel.
+ *   sga_ec_y_symbols_centred / sga_ec_z_symbols_centred (ABI 5): the same for the MEAN- / MEDIAN-centred latents that
+ *                      mbt2018.py compress codes (y_hat = round(y - mu) + mu, mbt2018.py:80; z_hat = round(z - median) + median,
+ *                      mbt2018.py:69): sym = round(y_hat - mu), tab = y_tab0 + level(sigma) (one zero-offset table per level);
+ *                      sym = round(z_hat - median[c]), tab = c.  bad counts elements that are not integers to 1e-3 after centring.
  *   sga_ec_encode    : block b -> the END of slots[b * slot_cap .. (b + 1) * slot_cap), block_bytes[b] bytes (0: overflow;
  *                      slot_cap = 16 + 8 * block always suffices).
  *   sga_ec_compact   : slots -> out + block_off[b] (the caller's exclusive scan of block_bytes).
@@ -316,6 +320,10 @@ int sga_ec_y_symbols(const float* y_hat, const float* mu, const float* sigma, in
                      void* stream);
 int sga_ec_z_symbols(const float* z_hat, int64_t n, int num_filters, int32_t* sym, int32_t* tab, int32_t* bad,
                      void* stream);
+int sga_ec_y_symbols_centred(const float* y_hat, const float* mu, const float* sigma, int64_t n, const double* scale_table,
+                             int levels, int y_tab0, int32_t* sym, int32_t* tab, int32_t* bad, void* stream);
+int sga_ec_z_symbols_centred(const float* z_hat, const float* medians, int64_t n, int num_filters, int32_t* sym, int32_t* tab,
+                             int32_t* bad, void* stream);
 int sga_ec_encode(const int32_t* sym, const int32_t* tab, int64_t n, int block, const uint32_t* cdf, const int32_t* lens,
                   const int32_t* offs, int stride, uint8_t* slots, int slot_cap, uint32_t* block_bytes, void* stream);
 int sga_ec_compact(const uint8_t* slots, int slot_cap, const uint32_t* block_bytes, const uint64_t* block_off,

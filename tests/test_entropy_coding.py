@@ -86,6 +86,45 @@ def test_block_size_follows_the_rate(coder):
     assert ec.adapted_block(np.array([11, 12, 10])) == ec.BLOCK_MAX and ec.adapted_block(np.array([600, 700])) == ec.BLOCK
 
 
+def test_centred_latents_round_trip_and_size():
+    """What mbt2018.py compress codes (mbt2018.py:69,80): y_hat = round(y - mu) + mu under the zero-offset table of its scale
+    level, z_hat = round(z - median) + median on the grid median + k.  Exact round trip INCLUDING the float32 re-centring, size at
+    the quantised model's ideal, table CRC distinct from the integer coder's, integer latents refused (and vice versa)."""
+    w = sga_amd.make_synthetic_weights(64, seed=0)
+    med = np.linspace(-0.45, 0.45, 64).astype(np.float32)
+    cc = ec.EntropyCoder(w, centred=True, medians=med)
+    ic = ec.EntropyCoder(w)
+    assert cc.table_mode == 2 and ic.table_mode == 0 and cc.table_crc() != ic.table_crc()
+    rng = np.random.RandomState(4)
+    shape = (2, 6, 5, 64)
+    mu = (rng.standard_normal(shape) * 3).astype(np.float32)
+    sigma = np.exp(rng.standard_normal(shape) * 1.2).astype(np.float32)
+    y = (mu + sigma * rng.standard_normal(shape).astype(np.float32)).astype(np.float32)
+    y_hat = np.rint(y - mu) + mu                                       # float32, as the device computes it
+    y_hat.reshape(-1)[7] = mu.reshape(-1)[7] + 5000.0                  # an escape
+    z = (rng.standard_normal((2, 2, 2, 64)) * 4).astype(np.float32)
+    z_hat = np.rint(z - med) + med
+    zb, yb = cc.encode_z(z_hat), cc.encode_y(y_hat, mu, sigma)
+    assert np.array_equal(cc.decode_z(zb, z_hat.shape), z_hat) and np.array_equal(cc.decode_y(yb, mu, sigma), y_hat)
+    ideal = cc.ideal_bits_y(y_hat, mu, sigma)
+    assert ideal <= 8 * len(yb) <= ideal * 1.01 + 64 + 64 * 5
+    # the exact model: no mean-bin quantisation in this mode, only the 64 scale levels
+    from math import erfc, sqrt
+    phi = np.vectorize(lambda t: 0.5 * erfc(-t / sqrt(2)))
+    sb = np.maximum(sigma.astype(np.float64), 0.11)
+    k = np.rint(y_hat - mu).astype(np.float64)
+    p = np.maximum(phi((k + 0.5) / sb) - phi((k - 0.5) / sb), 1e-9)
+    keep = np.ones(y.size, bool); keep[7] = False
+    exact = -np.log2(p.reshape(-1)[keep]).sum()
+    assert cc.ideal_bits_y(y_hat.reshape(-1)[keep], mu.reshape(-1)[keep], sigma.reshape(-1)[keep]) < exact * 1.03 + 100
+    with pytest.raises(ValueError):
+        cc.encode_y(np.rint(y), mu, sigma)                             # integers are not mu + integers
+    with pytest.raises(ValueError):
+        ic.encode_y(y_hat, mu, sigma)
+    with pytest.raises(ValueError):
+        cc.encode_z(np.rint(z))
+
+
 def test_container_and_corruption(coder):
     z = np.rint(np.random.RandomState(2).standard_normal((1, 2, 2, 64)) * 3).astype(np.float32)
     zb = coder.encode_z(z)

@@ -247,6 +247,50 @@ def test_real_bytes_at_the_trained_like_operating_point_c192(gpu_out_dir):
     codec.close()
 
 
+@pytest.mark.parametrize("which", ["synthetic_c192_medians", "fitted_c192"])
+def test_base_compress_to_real_bytes(which, gpu_out_dir):
+    """cfg 1 end to end: mbt2018.py compress writes a FILE (mbt2018.py:211-222) of the mean- / median-centred latents
+    (mbt2018.py:69,80) and its decompress reads it back (mbt2018.py:248-295).  Here: `base_compress` -> `compress_latents(centred=
+    True)` on the device == the host coder byte for byte -> `decompress_latents` returns the SAME float32 latents (the re-centring
+    `symbol + mu` is the float32 addition that made them) -> the decoder's reconstruction has the PSNR `base_compress` reported.
+    On the fitted model the file is within 5 % of the estimated bpp (no mean bins in this mode: only the 64 scale levels and
+    the framing); on the synthetic weights (non-zero medians, 4 bpp) within 2 %."""
+    import json, os
+    from sga_amd.codec import SGACodec, metrics_to_dict
+    C, B, H, W = 192, 2, 256, 256
+    if which == "fitted_c192":
+        w = sga_amd.load_weights_npz(os.path.join(os.path.dirname(__file__), "golden", "fitted_weights_c192.npz"))
+        x, med, tol = sga_amd.make_lowpass_images(B, H, W, seed=78), None, 0.05
+    else:
+        w = sga_amd.make_synthetic_weights(C, seed=0)
+        x, med, tol = np.random.RandomState(12).rand(B, H, W, 3).astype(np.float32), np.linspace(-0.45, 0.45, C).astype(np.float32), 0.02
+    codec = SGACodec(w, C, B, H, W)
+    y_hat, z_hat, met = codec.base_compress(x, medians=med)
+    m = metrics_to_dict(met)
+    dev = codec.compress_latents((B, H, W), y_hat, z_hat, centred=True, medians=med)
+    assert dev == codec.compress_latents((B, H, W), y_hat, z_hat, centred=True, medians=med, on_device=False)
+    for on_device in (True, False):
+        xs, y2, z2 = codec.decompress_latents(dev, on_device=on_device, medians=med)
+        assert tuple(xs) == (B, H, W) and torch.equal(y2, y_hat) and torch.equal(z2, z_hat)
+    with pytest.raises(ValueError):
+        codec.compress_latents((B, H, W), y_hat, z_hat)                  # the integer coder refuses centred latents
+    if med is not None:
+        with pytest.raises(ValueError):
+            codec.decompress_latents(dev)                                # other medians: other tables, refused by the CRC
+    x_hat = codec.reconstruct(y2, H, W)
+    xt = torch.as_tensor(x, device="cuda")
+    mse = ((torch.round(x_hat * 255) - xt * 255) ** 2).mean(dim=(1, 2, 3))
+    psnr = (20 * np.log10(255.0) - 10 * torch.log10(mse)).cpu().numpy()
+    actual, est = 8.0 * len(dev) / (B * H * W), float(m["est_bpp"].mean())
+    rep = dict(test="base_compress_real_bytes", which=which, bytes=len(dev), actual_bpp=actual, est_bpp=est, psnr_decoded=psnr.tolist(),
+               psnr_reported=m["psnr"].tolist())
+    with open(os.path.join(gpu_out_dir, "parity_entropy.jsonl"), "a") as f:
+        f.write(json.dumps(rep) + "\n")
+    assert np.abs(psnr - m["psnr"]).max() < 2e-3, rep
+    assert 0 < actual / est - 1 < tol, rep
+    codec.close()
+
+
 def test_rans_oracle_decodes_the_device_stream():
     """the device coder (csrc/rans.hip) checked by something that is not the product -- oracle/rans_ref.py
     (the published rANS recurrences in Python integers) decodes the stream the DEVICE wrote for the (y_hat, mu, sigma) of a
