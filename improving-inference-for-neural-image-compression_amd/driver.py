@@ -224,7 +224,7 @@ def run_verbose(codec, x, lmbda, *, its, lr, annealing_rate, t0, T_ub, seed, los
 def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=700, T_ub=0.5,
                 seed=0, rank=0, world=1, dist=None, verbose=False, log_itv=100, log=print,
                 method="sga", r_its=2000, r_lr=0.003, medians=None, base_scale_bound=None, check_finite=False,
-                opt_record=None, recon=None):
+                opt_record=None, recon=None, output_file=None):
     """The per-batch loop of sga.py:201-253 (method "sga"), bb_sga.py:199-280 ("bb_sga") or the
     one-shot mbt2018.py:159-180 ("mbt2018") over a dataset X [N,H,W,3] float32.
     Returns dict field -> [N] array (on every rank).
@@ -235,12 +235,15 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
       points, as sga.py:209,234-236 keeps them for the last batch (+ `rd_loss_after_rounding` with --verbose).  rd_loss is
       the objective of the images in that launch (loss_scale = 1 / len(reference batch)): the reference's value when the
       launch holds a whole reference batch.
-    recon: a list to receive (image index, x_hat [H,W,3] float32) of this rank's images (sga.py:281-291)."""
+    recon: a list to receive (image index, x_hat [H,W,3] float32) of this rank's images (sga.py:281-291).
+    Method "mbt2018" also CODES every launch's centred latents (mbt2018.py:84-85,211-222) and returns what the reference's
+      compress() adds to its npz (mbt2018.py:218-232): `batch_actual_bpp` (bits of the launch's stream / pixels of ONE image,
+      as the reference computes it), `batch_sizes`, `avg_batch_actual_bpp`; output_file: the last stream is written there."""
     want_trace = verbose or check_finite or opt_record is not None
     fields = BB_EVAL_FIELDS if method == "bb_sga" else EVAL_FIELDS
     N, H, W, _ = X.shape
     bs = get_eval_batch_size(H * W)
-    local_idx, local_met = [], []
+    local_idx, local_met, coded = [], [], []
     if method in ("mbt2018", "map") and medians is None:
         medians = getattr(codec, "medians", None)       # from the checkpoint's `quantiles`
     log_sched, log_rate, log_Tub, log_t0 = "exp0", annealing_rate, T_ub, t0
@@ -257,8 +260,13 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
                                                 seed=sd, loss_scale=loss_scale, trace=want_trace)
             elif method == "mbt2018":
                 kw = {} if base_scale_bound is None else dict(scale_bound=base_scale_bound)
-                _, _, met = codec.base_compress(X[idx], medians=medians, **kw)      # default 0.11: mbt2018.py:80
+                y_hat_b, z_hat_b, met = codec.base_compress(X[idx], medians=medians, **kw)      # default 0.11: mbt2018.py:80
                 tr = None
+                blob = codec.compress_latents((len(idx), H, W), y_hat_b, z_hat_b, centred=True, medians=medians)
+                coded.append((idx[0], 8.0 * len(blob) / (H * W), len(idx)))      # mbt2018.py:218-221
+                if output_file and rank == 0:
+                    with open(output_file, "wb") as f:                            # mbt2018.py:214-216 (overwritten per batch)
+                        f.write(blob)
             elif method in SIBLINGS:
                 relax, sched, s_lr, s_r, s_Tub, s_t0, early = SIBLINGS[method]
                 log_sched, log_rate, log_Tub, log_t0 = sched, s_r, s_Tub, s_t0
@@ -323,7 +331,17 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
     device = codec.device if (dist is not None and dist.is_initialized()
                               and dist.get_backend() == "nccl") else None
     allm = gather_metrics(local_idx, local_met, N, dist, device, len(fields))
-    return {k: allm[:, i].copy() for i, k in enumerate(fields)}
+    res = {k: allm[:, i].copy() for i, k in enumerate(fields)}
+    if method == "mbt2018":
+        if dist is not None and dist.is_initialized() and world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, coded)
+            coded = [c for part in parts for c in part]
+        coded.sort()
+        res["batch_actual_bpp"] = np.asarray([c[1] for c in coded])
+        res["batch_sizes"] = np.asarray([c[2] for c in coded])
+        res["avg_batch_actual_bpp"] = np.asarray(res["batch_actual_bpp"].sum() / max(res["batch_sizes"].sum(), 1))      # mbt2018.py:229
+    return res
 
 
 def parse_args(argv):
@@ -423,7 +441,8 @@ def compress(args, weights=None):
     res = run_dataset(codec, X, args.lmbda, its=args.sga_its, annealing_rate=args.annealing_rate,
                       t0=args.t0, seed=args.seed, rank=rank, world=world, dist=dist,
                       verbose=args.verbose, method=method, base_scale_bound=sb,
-                      check_finite=getattr(args, "check_finite", False), opt_record=opt_record, recon=recon)
+                      check_finite=getattr(args, "check_finite", False), opt_record=opt_record, recon=recon,
+                      output_file=getattr(args, "output_file", None) if method == "mbt2018" else None)
     if rank == 0:
         if args.results_dir:
             os.makedirs(args.results_dir, exist_ok=True)
@@ -441,7 +460,8 @@ def compress(args, weights=None):
                 print("Saving image reconstruction to ", os.path.join(args.results_dir, f))
                 Image.fromarray(img).save(os.path.join(args.results_dir, f))
         for field in res:
-            print("Avg {}: {:0.4f}".format(field, res[field].mean()))       # sga.py:293-295
+            if field not in ("batch_actual_bpp", "batch_sizes"):            # mbt2018.py:230-245 prints the average only
+                print("Avg {}: {:0.4f}".format(field, res[field].mean()))   # sga.py:293-295
     return res
 
 

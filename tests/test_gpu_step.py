@@ -443,14 +443,24 @@ def test_driver_cli_end_to_end(method, tmp_path):
         out = tmp_path / f"res{mb}"
         argv = ["--num_filters", "64", "compress", "--results_dir", str(out), "--sga_its", "12", "--t0", "4",
                 "--method", method, "--synthetic_weights", "--max_batch", str(mb), runname, str(inp)]
+        if method == "mbt2018" and mb == 5:      # mbt2018.py:214-216: the stream itself
+            argv.append(str(tmp_path / "tiny.sgac"))
         driver.main(argv)
+        if method == "mbt2018" and mb == 5:
+            assert (tmp_path / "tiny.sgac").read_bytes()[:4] == b"SGAC"
         files = os.listdir(out)
         assert files == [driver.result_filename("rd", method, 0.02, runname, str(inp))], files
         res[mb] = dict(np.load(out / files[0]))
     fields = BB_EVAL_FIELDS if method == "bb_sga" else EVAL_FIELDS
-    assert sorted(res[5]) == sorted(fields)
+    extra = ["batch_actual_bpp", "batch_sizes", "avg_batch_actual_bpp"] if method == "mbt2018" else []      # mbt2018.py:218-232
+    assert sorted(res[5]) == sorted(list(fields) + extra)
     for k in fields:
         assert res[5][k].shape == (5,)
+    if method == "mbt2018":      # the FILE's rate beside the estimate (these tiny images: the 64-byte container shows)
+        assert res[5]["batch_sizes"].tolist() == [5] and res[2]["batch_sizes"].tolist() == [2, 2, 1]
+        for mb in (5, 2):
+            a, e = float(res[mb]["avg_batch_actual_bpp"]), float(res[mb]["est_bpp"].mean())
+            assert abs(a - e) < 0.05 * e + 8 * 160 * len(res[mb]["batch_sizes"]) / (5 * 48 * 64), (a, e)      # untrained model: either sign
     assert np.isfinite(res[5]["est_bpp"]).all() and np.isfinite(res[5]["psnr"]).all()
     if method in ("mbt2018", "danneal", "ste", "map"):       # no noise: chunking cannot matter
         for k in ("est_bpp", "psnr"):
