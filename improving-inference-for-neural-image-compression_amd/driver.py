@@ -384,6 +384,14 @@ def parse_args(argv):
     c.add_argument("runname")
     c.add_argument("input_file")
     c.add_argument("output_file", nargs="?")
+    d = sub.add_parser("decompress", description="reads a stream written by `compress --method mbt2018 ... output_file` (or by "
+                                                 "SGACodec.compress_latents), reconstructs the image(s) and writes PNG "
+                                                 "(mbt2018.py:248-295, tf_boilerplate.py:178-197)")
+    d.add_argument("--synthetic_weights", action="store_true")
+    d.add_argument("runname")
+    d.add_argument("input_file")
+    d.add_argument("output_file", nargs="?", help="default: input_file + '.png' (tf_boilerplate.py:194-197); image k > 0 of a "
+                                                  "batch stream goes to <output minus .png>.<k>.png")
     args = p.parse_args(argv)
     return args
 
@@ -465,13 +473,43 @@ def compress(args, weights=None):
     return res
 
 
+def decompress(args, weights=None):
+    """mbt2018.py:248-295: stream -> z_hat -> (mu, sigma) = h_s(z_hat) -> y_hat -> g_s -> crop -> PNG.  The stream's mode byte says
+    whether it holds the centred latents of `compress --method mbt2018` or the integer latents of an SGA run."""
+    from PIL import Image
+    from .codec import SGACodec
+    from .weights import make_synthetic_weights
+    from . import entropy_coding as ec
+    with open(args.input_file, "rb") as f:
+        blob = f.read()
+    (B, H, W) = ec.unpack(blob)[0]
+    if weights is None:
+        if args.synthetic_weights:
+            weights = make_synthetic_weights(args.num_filters, seed=0)
+        else:
+            from .tf_checkpoint import load_effective_weights
+            weights = load_effective_weights(os.path.join(args.checkpoint_dir, args.runname), args.num_filters)
+    codec = SGACodec(weights, args.num_filters, B, H, W, device="cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
+    try:
+        _, y_hat, _ = codec.decompress_latents(blob)
+        x_hat = codec.reconstruct(y_hat, H, W).cpu().numpy()
+    finally:
+        codec.close()
+    out = args.output_file or args.input_file + ".png"
+    stem = out[:-4] if out.lower().endswith(".png") else out
+    for k in range(B):
+        img = np.round(np.clip(x_hat[k], 0.0, 1.0) * 255.0).astype(np.uint8)
+        Image.fromarray(img).save(out if k == 0 else "%s.%d.png" % (stem, k))
+    return x_hat
+
+
 def main(argv=None):
     args = parse_args(sys.argv[1:] if argv is None else argv)
-    if args.command != "compress":                                          # sga.py:303
-        raise ValueError("Only compression is supported.")
+    if args.command not in ("compress", "decompress"):                      # sga.py:303
+        raise ValueError("Only compress / decompress are supported.")
     if args.num_filters <= 0:
         raise SystemExit("--num_filters is required")
-    return compress(args)
+    return compress(args) if args.command == "compress" else decompress(args)
 
 
 if __name__ == "__main__":

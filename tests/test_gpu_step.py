@@ -446,8 +446,16 @@ def test_driver_cli_end_to_end(method, tmp_path):
         if method == "mbt2018" and mb == 5:      # mbt2018.py:214-216: the stream itself
             argv.append(str(tmp_path / "tiny.sgac"))
         driver.main(argv)
-        if method == "mbt2018" and mb == 5:
+        if method == "mbt2018" and mb == 5:      # ... and mbt2018.py decompress (248-295): stream -> PNGs at the reported PSNR
+            from PIL import Image
             assert (tmp_path / "tiny.sgac").read_bytes()[:4] == b"SGAC"
+            driver.main(["--num_filters", "64", "decompress", "--synthetic_weights", runname, str(tmp_path / "tiny.sgac")])
+            r5 = dict(np.load(out / os.listdir(out)[0]))
+            for k in range(5):
+                png = tmp_path / ("tiny.sgac.png" if k == 0 else "tiny.sgac.%d.png" % k)
+                dec = np.asarray(Image.open(png)).astype(np.float64)
+                psnr = 10 * np.log10(255.0 ** 2 / ((dec - X[k].astype(np.float64)) ** 2).mean())
+                assert abs(psnr - r5["psnr"][k]) < 1e-3, (k, psnr, r5["psnr"][k])
         files = os.listdir(out)
         assert files == [driver.result_filename("rd", method, 0.02, runname, str(inp))], files
         res[mb] = dict(np.load(out / files[0]))
