@@ -293,10 +293,13 @@ def run_dataset(codec, X, lmbda, *, its=2000, lr=0.005, annealing_rate=1e-3, t0=
                     for k, xh in zip(idx, codec.reconstruct(lat[0], H, W).cpu().numpy()):
                         recon.append((k, xh))
             else:
-                y_hat_l, _, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate,
-                                                t0=t0, T_ub=T_ub, seed=sd, loss_scale=loss_scale,
-                                                trace=want_trace)
+                y_hat_l, z_hat_l, met, tr = codec.run(X[idx], lmbda, its=its, lr=lr, annealing_rate=annealing_rate,
+                                                      t0=t0, T_ub=T_ub, seed=sd, loss_scale=loss_scale,
+                                                      trace=want_trace)
                 after = None
+                if output_file and rank == 0:      # beyond sga.py (which stops at the estimate): the run's integer latents as a
+                    with open(output_file, "wb") as f:      # stream `driver decompress` reads (last launch wins, as mbt2018.py:214-216)
+                        f.write(codec.compress_latents((len(idx), H, W), y_hat_l, z_hat_l))
                 if recon is not None:
                     for k, xh in zip(idx, codec.reconstruct(y_hat_l, H, W).cpu().numpy()):
                         recon.append((k, xh))
@@ -450,7 +453,7 @@ def compress(args, weights=None):
                       t0=args.t0, seed=args.seed, rank=rank, world=world, dist=dist,
                       verbose=args.verbose, method=method, base_scale_bound=sb,
                       check_finite=getattr(args, "check_finite", False), opt_record=opt_record, recon=recon,
-                      output_file=getattr(args, "output_file", None) if method == "mbt2018" else None)
+                      output_file=getattr(args, "output_file", None) if method in ("mbt2018", "sga") else None)
     if rank == 0:
         if args.results_dir:
             os.makedirs(args.results_dir, exist_ok=True)

@@ -443,10 +443,10 @@ def test_driver_cli_end_to_end(method, tmp_path):
         out = tmp_path / f"res{mb}"
         argv = ["--num_filters", "64", "compress", "--results_dir", str(out), "--sga_its", "12", "--t0", "4",
                 "--method", method, "--synthetic_weights", "--max_batch", str(mb), runname, str(inp)]
-        if method == "mbt2018" and mb == 5:      # mbt2018.py:214-216: the stream itself
+        if method in ("mbt2018", "sga") and mb == 5:      # mbt2018.py:214-216: the stream itself (sga: the run's integer latents)
             argv.append(str(tmp_path / "tiny.sgac"))
         driver.main(argv)
-        if method == "mbt2018" and mb == 5:      # ... and mbt2018.py decompress (248-295): stream -> PNGs at the reported PSNR
+        if method in ("mbt2018", "sga") and mb == 5:      # ... and mbt2018.py decompress (248-295): stream -> PNGs at the reported PSNR
             from PIL import Image
             assert (tmp_path / "tiny.sgac").read_bytes()[:4] == b"SGAC"
             driver.main(["--num_filters", "64", "decompress", "--synthetic_weights", runname, str(tmp_path / "tiny.sgac")])
