@@ -265,6 +265,14 @@ class _FakeCodec:
         m = torch.stack([base * (k + 1) for k in range(7)], dim=1)
         return None, None, m.float(), None
 
+    def base_compress(self, x, medians=None, **kw):                      # --method mbt2018: metrics + "latents"
+        m = self.run(x, 0.0, loss_scale=0.0)[2]
+        return torch.zeros(len(x)), torch.zeros(len(x)), m
+
+    def compress_latents(self, shape, y_hat, z_hat, centred=False, medians=None):
+        assert centred and shape[0] == len(y_hat)
+        return b"s" * (10 + 3 * len(y_hat))                               # a 10-byte "container" + 3 bytes per image
+
 
 PIX = 8 * 8
 
@@ -275,6 +283,8 @@ def _worker(rank, world, port, X, out_dir, bs):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     res = driver.run_dataset(_FakeCodec(1 + rank), X, 0.01, its=3, seed=5, rank=rank, world=world, dist=dist)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
+    res = driver.run_dataset(_FakeCodec(1 + rank), X, 0.01, rank=rank, world=world, dist=dist, method="mbt2018")
+    np.savez(os.path.join(out_dir, f"base_r{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -307,6 +317,14 @@ def test_sharded_run_and_gather_gloo_world2(tmp_path, monkeypatch, N, bs):
         got = np.load(tmp_path / f"r{r}.npz")
         for k in driver.EVAL_FIELDS:
             assert np.allclose(got[k], single[k], atol=1e-6), (r, k)
+    # --method mbt2018 codes every launch: the per-launch sizes of BOTH ranks reach every rank (mbt2018.py:218-232)
+    b0, b1 = np.load(tmp_path / "base_r0.npz"), np.load(tmp_path / "base_r1.npz")
+    for k in ("batch_actual_bpp", "batch_sizes", "avg_batch_actual_bpp"):
+        assert np.array_equal(b0[k], b1[k]), k
+    assert b0["batch_sizes"].sum() == N
+    total_bytes = b0["batch_actual_bpp"].sum() * PIX / 8
+    assert abs(total_bytes - (10 * len(b0["batch_sizes"]) + 3 * N)) < 1e-6
+    assert abs(float(b0["avg_batch_actual_bpp"]) - b0["batch_actual_bpp"].sum() / N) < 1e-12
 
 
 def test_launches_pool_images_of_consecutive_reference_batches():
