@@ -383,10 +383,13 @@ def main():
             cdc.run(xf, args.lmbda, its=110, seed=1, metrics=False)
             torch.cuda.synchronize(device)
             t1 = time.perf_counter()
-            yf, _, mf, _ = cdc.run(xf, args.lmbda, its=args.its, seed=2)
+            yf, zf, mf, _ = cdc.run(xf, args.lmbda, its=args.its, seed=2)
             torch.cuda.synchronize(device)
             el = time.perf_counter() - t1
             yb, zb, mb = cdc.base_compress(xf, scale_bound=0.0)
+            # outside the timed region: the FILES (rANS on the device; the coder's tables bound sigma at 0.11, the run did not)
+            file_bpp = 8.0 * len(cdc.compress_latents((B, H, W), yf, zf)) / (B * H * W)
+            file_bpp_one_shot = 8.0 * len(cdc.compress_latents((B, H, W), yb, zb, centred=True)) / (B * H * W)
             other_weights = dict(weights="fitted_c%d (tests/golden/fitted_weights_c%d.npz), low-pass images" % (C, C),
                                  value=round(B / el, 4), unit="images/sec", ms_per_iteration=round(1e3 * el / args.its, 4),
                                  path_frac_of_fp32_mfma_peak=round(B / el * gflop_per_image_step(H, W, C) * args.its / 1e3
@@ -394,6 +397,7 @@ def main():
                                  hyper_branch_fork_point=cdc.fork_point(),
                                  final_est_bpp_mean=float(mf[:, 4].mean()), final_psnr_mean=float(mf[:, 1].mean()),
                                  one_shot_est_bpp_mean=float(mb[:, 4].mean()), one_shot_psnr_mean=float(mb[:, 1].mean()),
+                                 final_file_bpp=round(file_bpp, 5), one_shot_file_bpp=round(file_bpp_one_shot, 5),
                                  frac_zero_y_hat=float((yf == 0).float().mean()))
             cdc.close()
             del cdc, xf
