@@ -195,7 +195,8 @@ def test_bits_back_rate_at_kodak_size_trained_like_weights(gpu_out_dir):
     codec.close()
 
 
-def test_real_bytes_at_the_trained_like_operating_point_c192(gpu_out_dir):
+@pytest.mark.parametrize("B,H,W", [(4, 256, 256), (1, 512, 768)])
+def test_real_bytes_at_the_trained_like_operating_point_c192(B, H, W, gpu_out_dir):
     """What the reference's README quotes is a FILE size (mbt2018.py:211-222 writes the packed strings) next to a PSNR of the decoded
     image (mbt2018.py:283-288), at 0.1-1.2 bpp.  So: the fitted C = 192 model (0.39 bpp / 33.5 dB one-shot, 87 % of y_hat at 0, 78 % of
     the predicted scales under the coder's lower bound 0.11), four 256 x 256 low-pass images, sigma bounded as the coder's tables
@@ -207,13 +208,13 @@ def test_real_bytes_at_the_trained_like_operating_point_c192(gpu_out_dir):
     size (within 3 %), i.e. a lower lambda * mse + bpp with the file's own rate."""
     import json, os
     from sga_amd.codec import SGACodec, metrics_to_dict
-    C, B, H, W = 192, 4, 256, 256
+    C = 192                      # (4 x 256^2: the benchmark's tile; 1 x 512 x 768: one Kodak-size image, SURVEY.md cfg 3)
     w = sga_amd.load_weights_npz(os.path.join(os.path.dirname(__file__), "golden", "fitted_weights_c192.npz"))
     codec = SGACodec(w, C, B, H, W)
     codec.set_scale_bound(0.11)
     x = sga_amd.make_lowpass_images(B, H, W, seed=77)
     xt = torch.as_tensor(x, device="cuda")
-    rep = dict(test="real_bytes_fitted_c192")
+    rep = dict(test="real_bytes_fitted_c192", B=B, H=H, W=W)
     lmbda = 0.01                      # what the weights were fitted at
     sizes, psnrs, cost = {}, {}, {}
     for name in ("one_shot", "sga"):
