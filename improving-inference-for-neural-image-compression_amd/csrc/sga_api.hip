@@ -172,6 +172,7 @@ struct sga_handle {
   unsigned long long graph_clock = 0;
   long long n_captures = 0;        // stream captures + instantiations so far (sga_debug_counter)
   long long n_graph_evictions = 0;
+  long long n_retired_destroyed = 0;            // retired graphs destroyed early because more than kMaxRetired had accumulated
   std::vector<hipGraphExec_t> retired_graphs;   // candidate graphs that lost the timing: destroyed with the handle (experiment:
                                    // destroying them while their sibling is in use crashed the process in the full test suite)
   int tuned_B = 0, tuned_H = 0, tuned_W = 0;   // geometry the last timed choice (tuned_name) was made for: graphs of that
@@ -1398,6 +1399,8 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
 // a lifetime audit of everything a node references) without finding a host-side cause, and under the destroy policy the full
 // suite passed 2 of 3 times and crashed once at the round-3 spot (second 2000-iteration run at 1200 x 1200, C = 256); under
 // the retire policy it has never crashed (9 full runs over two rounds).
+constexpr size_t kMaxRetired = 256;
+
 void drop_graph(sga_handle* h, hipGraphExec_t& ex, hipStream_t st = nullptr) {
   if (!ex) return;
   if (h->drop_destroy) {
@@ -1406,6 +1409,19 @@ void drop_graph(sga_handle* h, hipGraphExec_t& ex, hipStream_t st = nullptr) {
     (void)hipGraphExecDestroy(ex);
   } else {
     h->retired_graphs.push_back(ex);
+    // The retire policy must not be an unbounded leak either: a service that cycles through more keys than the cache holds
+    // retires three graphs per miss (round 5 soak: 1 928 retired graphs after 648 runs).  Past kMaxRetired the OLDEST half is
+    // destroyed behind a synchronisation of both streams -- graphs that were last replayed hundreds of launches ago, not the
+    // sibling of a graph in use, which is where the round-3 / round-4 crashes sat (and 1 872 immediate mid-life destroys in the
+    // same soak under SGA_GRAPH_DROP=destroy did not crash either: profiles/r05_soak_evictions.txt).
+    if (h->retired_graphs.size() > kMaxRetired) {
+      if (st) (void)hipStreamSynchronize(st);
+      if (h->sB) (void)hipStreamSynchronize(h->sB);
+      const size_t n = h->retired_graphs.size() / 2;
+      for (size_t i = 0; i < n; ++i) (void)hipGraphExecDestroy(h->retired_graphs[i]);
+      h->retired_graphs.erase(h->retired_graphs.begin(), h->retired_graphs.begin() + (long)n);
+      h->n_retired_destroyed += (long long)n;
+    }
   }
   ex = nullptr;
 }

@@ -367,7 +367,7 @@ typedef enum sga_counter {
   SGA_COUNTER_GRAPH_CAPTURES = 0,   /* stream captures + instantiations so far (3 per timed geometry, 1 per untimed one) */
   SGA_COUNTER_GRAPHS_CACHED = 1,    /* live entries */
   SGA_COUNTER_GRAPH_EVICTIONS = 2,  /* entries retired because the cache was full (16) */
-  SGA_COUNTER_GRAPHS_RETIRED = 3    /* dropped executable graphs kept until sga_destroy (losing fork-point candidates, evictions) */
+  SGA_COUNTER_GRAPHS_RETIRED = 3    /* dropped executable graphs kept alive (losing fork-point candidates, evictions): until sga_destroy, or until 256 have accumulated (then the oldest half is destroyed) */
 } sga_counter;
 int sga_debug_counter(const sga_handle* h, int which, long long* value);
 
