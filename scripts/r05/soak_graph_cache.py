@@ -10,13 +10,14 @@ from sga_amd.codec import SGACodec
 
 C = 192
 MINUTES = float(sys.argv[1]) if len(sys.argv) > 1 else 9.0
-codec = SGACodec(sga_amd.make_synthetic_weights(C, seed=0), C, 8, 512, 768)
+PRECISION = sys.argv[2] if len(sys.argv) > 2 else "f32"
+codec = SGACodec(sga_amd.make_synthetic_weights(C, seed=0), C, 8, 512, 768, precision=PRECISION)
 rng = np.random.RandomState(0)
 imgs = {(8, 256, 256): rng.rand(8, 256, 256, 3).astype(np.float32), (3, 256, 256): rng.rand(3, 256, 256, 3).astype(np.float32),
         (1, 256, 256): rng.rand(1, 256, 256, 3).astype(np.float32), (1, 512, 768): rng.rand(1, 512, 768, 3).astype(np.float32)}
 plan = [((8, 256, 256), "sga", 0.0), ((1, 512, 768), "sga", 0.0), ((3, 256, 256), "sga", 0.0), ((8, 256, 256), "sga", 0.11),
         ((1, 256, 256), "sga", 0.0), ((8, 256, 256), "unoise", 0.0), ((1, 512, 768), "sga", 0.11)]
-out = open("gpurun_out/r05_soak_graph_cache.txt", "w")
+out = open("gpurun_out/r05_soak_graph_cache%s.txt" % ("" if PRECISION == "f32" else "_" + PRECISION), "w")
 def say(s):
     print(s); out.write(s + "\n"); out.flush()
 first, runs, mism, t0 = {}, 0, 0, time.time()
@@ -41,7 +42,7 @@ while time.time() - t0 < 60 * MINUTES:
         (time.time() - t0, runs, codec.counter("captures"), captures_after_first_pass, codec.counter("cached"),
          codec.counter("evictions"), codec.counter("retired"), mism))
 codec.set_relaxation("sga", "exp0")
-say("soak: %d complete 2000-iteration runs on one handle over %d (geometry, relaxation, bound) keys in %.0f s; repeats bit-equal: %s; "
-    "captures after the first pass: %d" % (runs, len(plan), time.time() - t0, mism == 0, codec.counter("captures") - captures_after_first_pass))
+say("soak (%s): %d complete 2000-iteration runs on one handle over %d (geometry, relaxation, bound) keys in %.0f s; repeats bit-equal: %s; "
+    "captures after the first pass: %d" % (PRECISION, runs, len(plan), time.time() - t0, mism == 0, codec.counter("captures") - captures_after_first_pass))
 codec.close()
 sys.exit(1 if mism or codec is None else 0)
