@@ -83,7 +83,7 @@ constexpr bool glds_instance(int TM, int TN, int WM, int WN, int PRO, bool SMALL
   // 2-wave BN = 96 instance of the hyper branch (same speed alone, but with 56 KB per workgroup it gets in the
   // main chain's way: the iteration measured 1868 against 1827 us)
   return !X3 && !SMALLC && PRO == PRO_NONE &&
-         (((POST <= 1 || POST == 3 || POST == 4 || POST == 5) && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2) ||
+         ((POST <= 1 && TM == 1 && TN == 3 && WM == 2 && WN == 2) || (TM == 2 && TN == 3 && WM == 4 && WN == 2) ||
           (TM == 2 && TN == 4 && WM == 4 && WN == 2));
 }
 
@@ -116,7 +116,7 @@ constexpr int post_qbufs(int BM) { return BM < 128 ? 1 : 2; }
 // X3: 0 = f32 MFMA; 1 = bf16x3 (3 planes, 6 products); 2 = bf16x2 (the two upper planes, 3 products: operands rounded to 16
 // mantissa bits; only the pipelined PRO_NONE loop and the post-phase of such an instance have this form)
 template <int TM, int TN, int WM, int WN, int PRO, bool SMALLC, int X3, int POST = 0>
-__global__ __launch_bounds__(WM * WN * 64 + (POST == 5 ? 64 : 0), (X3 && (TN >= 4 || TM >= 4 || WM * WN >= 8)) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, (X3 && (TN >= 4 || TM >= 4 || WM * WN >= 8)) ? 1 : 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int RPP = NT / 8;                 // tile rows covered by one pass of the loaders
@@ -126,29 +126,15 @@ __global__ __launch_bounds__(WM * WN * 64 + (POST == 5 ? 64 : 0), (X3 && (TN >= 
 
   constexpr int CPITCH = TN * 32 + 4;         // epilogue staging pitch (floats) per wave row
   constexpr bool GLDS = glds_instance(TM, TN, WM, WN, PRO, SMALLC, X3, POST);
-  // POST = 3 is not a post-phase but the LOW-FOOTPRINT form of the 64-row instance (hyper branch, opt-in): ONE LDS stage and the
-  // epilogue staged two waves at a time -> 33 KB instead of 64.5 KB, so that a workgroup fits beside a 117-KB workgroup of the
-  // 256-row instance (gs2.bwd holds every CU from start to end; the branch's backward half otherwise waits for it)
-  constexpr bool LOWF = POST == 3;
-  // POST = 4: the DEEP form of the 64-row instance (round 5): FOUR LDS stages (128 KB, one workgroup per CU) and counted vmcnt
-  // waits, for launches whose grid cannot put two or three workgroups on every CU (the 16^2 ... 32^2 stages, B = 1): with two
-  // stages a step's DMA has one step of one workgroup to land, and a 10-step K chain runs at the L2 latency, not at the MFMA rate
-  constexpr bool DEEP = POST == 4;
-  // POST = 5: the 64-row instance with a LOADER WAVE (round 5): a fifth wave issues every LDS-DMA instruction of the workgroup, the
-  // four MFMA waves only read fragments and multiply.  In the plain instance each wave issues 8 DMA instructions per K-step
-  // (60-185 cycles each beside MFMAs, MI355X_MICROARCH.md) in front of its 48 MFMAs (3 072 cycles); only co-resident workgroups
-  // hide that.  Same stages, same fragment reads, same MFMA order: bit-identical to the plain instance.
-  constexpr bool LOADER = POST == 5;
-  constexpr int GSTAGES = DEEP ? 4 : (LOWF ? 1 : 2);
-  constexpr bool HASPOST = POST == 1 || POST == 2;
+  constexpr bool HASPOST = POST == 1;
   constexpr bool X3P = x3_pipelined(PRO, SMALLC, X3);
-  constexpr int MAIN_FLOATS = X3 ? x3_main_floats(BM, BN, X3P) : (GLDS ? GSTAGES * (BM + BN) * 32 : (BM + BN) * LDK);
-  constexpr int EPI_FLOATS = (LOWF ? 2 : WM * WN) * 32 * CPITCH;
+  constexpr int MAIN_FLOATS = X3 ? x3_main_floats(BM, BN, X3P) : (GLDS ? 2 * (BM + BN) * 32 : (BM + BN) * LDK);
+  constexpr int EPI_FLOATS = WM * WN * 32 * CPITCH;
   constexpr int POST_FLOATS = HASPOST ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
   constexpr int LDS_FLOATS0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   constexpr int LDS_FLOATS = LDS_FLOATS0 > POST_FLOATS ? LDS_FLOATS0 : POST_FLOATS;
   static_assert(!POST || (((BM == 256 && (BN == 192 || BN == 256) && NT == 512 && TM == 2 && HASPOST) ||
-                           (BM == 64 && BN == 192 && NT == 256 && TM == 1 && (POST == 1 || POST == 3 || POST == 4 || POST == 5))) && !SMALLC && PRO == PRO_NONE),
+                           (BM == 64 && BN == 192 && NT == 256 && TM == 1 && POST == 1)) && !SMALLC && PRO == PRO_NONE),
                 "post-phase instance");
   constexpr int PBX = X3 ? (BN * 12 + NT - 1) / NT : 1;     // 16-byte pieces of the 3-plane weight tile per thread
   constexpr bool PBX_TAIL = X3 && (BN * 12) % NT != 0;       // ... the last round covers part of the threads (8 waves x BN = 192)
@@ -560,183 +546,11 @@ __global__ __launch_bounds__(WM * WN * 64 + (POST == 5 ? 64 : 0), (X3 && (TN >= 
       for (int p = 0; p < IB; ++p)
         dma16_to_lds(gb_src[p] + ci, st + lds_b + p * 256);
     };
-    if constexpr (LOADER) {
-      constexpr int IAL = BM / 8, IBL = BN / 8;            // DMA instructions per stage: 8 rows x 8 slots each
-      if (wid == NW) {
-        // ---- the loader wave: all IAL + IBL pieces of every stage ----
-        int l_iy[IAL], l_ix[IAL], l_base[IAL], l_chunk[IAL], lb_chunk[IBL];
-#pragma unroll
-        for (int p = 0; p < IAL; ++p) {
-          const int r = p * 8 + r8;
-          const int m = m0 + r;
-          l_chunk[p] = (slot ^ ((r >> 1) & 7)) * 4;
-          if (m < Mtot) {
-            const int j = m % a.Wg;
-            const int t = m / a.Wg;
-            l_iy[p] = (t % a.Hg) * a.s_in; l_ix[p] = j * a.s_in; l_base[p] = (t / a.Hg) * a.Hin * a.Win;
-          } else {
-            l_iy[p] = -(1 << 20); l_ix[p] = 0; l_base[p] = 0;
-          }
-        }
-#pragma unroll
-        for (int p = 0; p < IBL; ++p) lb_chunk[p] = (slot ^ (((BM + p * 8 + r8) >> 1) & 7)) * 4;
-        const float* la_src[IAL];
-        const float* lb_src[IBL];
-        auto l_tap = [&](int t) {
-          const ConvTap tp = a.taps[ph.tap_begin + t];
-#pragma unroll
-          for (int p = 0; p < IAL; ++p) {
-            const int iy = l_iy[p] + tp.dy, ix = l_ix[p] + tp.dx;
-            const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-            la_src[p] = ok ? a.in + ((size_t)(l_base[p] + iy * a.Win + ix) * a.in_cs + a.in_coff + l_chunk[p]) : nullptr;
-          }
-#pragma unroll
-          for (int p = 0; p < IBL; ++p)
-            lb_src[p] = a.w + (((size_t)tp.slab * a.Npad + n0 + p * 8 + r8) * a.Cin + lb_chunk[p]);
-        };
-        auto l_issue = [&](int stage, int ci) {
-          float* st = smem + stage * STAGE;
-#pragma unroll
-          for (int p = 0; p < IAL; ++p) dma16_to_lds(la_src[p] ? la_src[p] + ci : a.zeros, st + p * 256);
-#pragma unroll
-          for (int p = 0; p < IBL; ++p) dma16_to_lds(lb_src[p] + ci, st + BM * 32 + p * 256);
-        };
-        if (k_begin < k_end) { l_tap(tapi); l_issue(0, ci0); }
-        __syncthreads();
-        for (int ks = k_begin; ks < k_end; ++ks) {
-          const int cur = (ks - k_begin) & 1;
-          if (ks + 1 < k_end) {
-            ci0 += BK;
-            if (ci0 >= a.Cin) { ci0 = 0; ++tapi; l_tap(tapi); }
-            l_issue(cur ^ 1, ci0);
-          }
-          __syncthreads();                                 // (vmcnt(0) before the barrier: the next stage has landed)
-        }
-        return;                                            // the epilogue belongs to the four MFMA waves
-      }
-      // ---- the MFMA waves ----
-      __syncthreads();
-      const int ra_ = (wm * TM) * 32 + (lane & 31);
-      const int rb_ = BM + (wn * TN) * 32 + (lane & 31);
-      const int hlf = lane >> 5;
-      for (int ks = k_begin; ks < k_end; ++ks) {
-        const float* St = smem + ((ks - k_begin) & 1) * STAGE;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = 2 * q + hlf;
-          f32x4 af[TM], bf[TN];
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm) {
-            const int r = ra_ + tm * 32;
-            af[tm] = *reinterpret_cast<const f32x4*>(&St[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
-          }
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            const int r = rb_ + tn * 32;
-            bf[tn] = *reinterpret_cast<const f32x4*>(&St[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-              for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][r], bf[tn][r], acc[tm][tn], 0, 0, 0);
-        }
-        __syncthreads();
-      }
-    } else
-    if constexpr (DEEP) {
-      // stage ks lives in slot (ks - k_begin) % 4.  Iteration ks: wait until this wave's DMA of stage ks has landed (at most two
-      // younger groups of IA + IB instructions may stay in flight), barrier (every wave's piece has landed AND every wave is done
-      // with stage ks - 1), request stage ks + 3 into the slot stage ks - 1 has just left, multiply stage ks.  One barrier per step.
-      constexpr int NI = IA + IB;
-      const int nk = k_end - k_begin;
-      int ci_i = ci0, tap_i = tapi;                        // the issue cursor runs ahead of the compute cursor
-      auto advance = [&]() { ci_i += BK; if (ci_i >= a.Cin) { ci_i = 0; ++tap_i; tap_setup(tap_i); } };
-      if (nk > 0) {
-        tap_setup(tap_i);
-        issue(0, ci_i);
-#pragma unroll
-        for (int pre = 1; pre < 3; ++pre)
-          if (pre < nk) { advance(); issue(pre, ci_i); }
-      }
-      const int ra_ = (wm * TM) * 32 + (lane & 31);
-      const int rb_ = BM + (wn * TN) * 32 + (lane & 31);
-      const int hlf = lane >> 5;
-      for (int i = 0; i < nk; ++i) {
-        const int young = nk - 1 - i;                      // groups issued after stage i so far: min(2, young)
-        if (young >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory");
-        else if (young == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();
-        if (i + 3 < nk) { advance(); issue((i + 3) & 3, ci_i); }
-        const float* St = smem + (i & 3) * STAGE;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = 2 * q + hlf;
-          f32x4 af[TM], bf[TN];
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm) {
-            const int r = ra_ + tm * 32;
-            af[tm] = *reinterpret_cast<const f32x4*>(&St[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
-          }
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            const int r = rb_ + tn * 32;
-            bf[tn] = *reinterpret_cast<const f32x4*>(&St[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-              for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][r], bf[tn][r], acc[tm][tn], 0, 0, 0);
-        }
-      }
-      __syncthreads();                                     // the stages become the epilogue's staging area
-    } else {
     if (k_begin < k_end) {
       tap_setup(tapi);
       issue(0, ci0);
     }
     __syncthreads();
-    if constexpr (LOWF) {
-      // one stage: load, barrier, multiply, barrier.  Nothing overlaps inside this workgroup; it runs beside a big one.
-      const int ra1 = (wm * TM) * 32 + (lane & 31), rb1 = BM + (wn * TN) * 32 + (lane & 31), hl1 = lane >> 5;
-      for (int ks = k_begin; ks < k_end; ++ks) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = 2 * q + hl1;
-          f32x4 af[TM], bf[TN];
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm) {
-            const int r = ra1 + tm * 32;
-            af[tm] = *reinterpret_cast<const f32x4*>(&smem[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
-          }
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            const int r = rb1 + tn * 32;
-            bf[tn] = *reinterpret_cast<const f32x4*>(&smem[r * 32 + ((c ^ ((r >> 1) & 7)) * 4)]);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-              for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][r], bf[tn][r], acc[tm][tn], 0, 0, 0);
-        }
-        __syncthreads();                                   // every wave is done with the stage
-        if (ks + 1 < k_end) {
-          ci0 += BK;
-          if (ci0 >= a.Cin) { ci0 = 0; ++tapi; tap_setup(tapi); }
-          issue(0, ci0);
-        }
-        __syncthreads();                                   // (waits for the DMA: vmcnt(0) before the barrier)
-      }
-    } else {
     const int ra_ = (wm * TM) * 32 + (lane & 31);
     const int rb_ = BM + (wn * TN) * 32 + (lane & 31);
     const int hlf = lane >> 5;
@@ -771,8 +585,6 @@ __global__ __launch_bounds__(WM * WN * 64 + (POST == 5 ? 64 : 0), (X3 && (TN >= 
               acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][r], bf[tn][r], acc[tm][tn], 0, 0, 0);
       }
       __syncthreads();
-    }
-    }
     }
   } else
   for (int ks = k_begin; ks < k_end; ++ks) {
@@ -1073,62 +885,6 @@ __global__ __launch_bounds__(WM * WN * 64 + (POST == 5 ? 64 : 0), (X3 && (TN >= 
       __builtin_amdgcn_wave_barrier();
       emit(a.post_v, std::integral_constant<bool, (SGA_NT & 8) != 0>{});      // v
       __builtin_amdgcn_wave_barrier();
-      // ---- the NEXT layer's products while v is on chip (C -> 3 transposed convolution, nn_models.py:60-63) ----
-      // P[pixel, (ky, kx, c)] = v[pixel, :] . W3[ky, kx, :, c] for all 25 x 3 (padded to 80) kernel columns: a third
-      // contraction out of the tile, 16 rows per wave on v_mfma_f32_16x16x4_f32 with the weights as the A operand (a lane's
-      // 4 accumulators = 16 contiguous bytes of P), W3 in K-chunks through the gamma buffers.  The layer itself then is a
-      // col2im over P (deconv3_gemm.hip) and never reads v.  Same MFMA sequence as deconv3_gemm_kernel: bit-equal P.
-      // POST = 2 only: a separate instance, because the code's mere presence costs the plain post-phase 11 spilled
-      // VGPRs (3663 vs 3620 ms per batch when compiled in and unused)
-      if constexpr (HR == 128 && POST == 2) {
-        if (a.post_p) {
-          lds_barrier();                             // every wave's block of v is in the tile
-          f32x4 rw3[2];
-          auto load_w3 = [&](int kc) {               // 80 rows x 32 floats = 640 float4: threads 0..511 + 0..127
-            rw3[0] = ld4(a.post_w3 + (size_t)lrow * C + kc * 32 + chunk * 4);
-            if (tid < 128) rw3[1] = ld4(a.post_w3 + (size_t)(64 + lrow) * C + kc * 32 + chunk * 4);
-          };
-          auto store_w3 = [&](int buf) {
-            *reinterpret_cast<f32x4*>(&Bq[buf * (C * LDK) + lrow * LDK + chunk * 4]) = rw3[0];
-            if (tid < 128) *reinterpret_cast<f32x4*>(&Bq[buf * (C * LDK) + (64 + lrow) * LDK + chunk * 4]) = rw3[1];
-          };
-          typedef float f32x4v __attribute__((ext_vector_type(4)));
-          f32x4v acc3[5];
-#pragma unroll
-          for (int c5 = 0; c5 < 5; ++c5) acc3[c5] = f32x4v{0.f, 0.f, 0.f, 0.f};
-          const int li16 = lane & 15, g4 = lane >> 4;
-          load_w3(0);
-          store_w3(0);
-          load_w3(1);
-          lds_barrier();
-#pragma unroll
-          for (int kc = 0; kc < C / 32; ++kc) {
-            if (kc + 1 < C / 32) store_w3((kc + 1) & 1);
-            if (kc + 2 < C / 32) load_w3(kc + 2);
-            const float* W3s = Bq + (kc & 1) * (C * LDK);
-#pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-              const f32x4 vf = *reinterpret_cast<const f32x4*>(&Tt[(wid * 16 + li16) * TP + kc * 32 + q2 * 16 + g4 * 4]);
-              f32x4 wf[5];
-#pragma unroll
-              for (int c5 = 0; c5 < 5; ++c5)
-                wf[c5] = *reinterpret_cast<const f32x4*>(&W3s[(c5 * 16 + li16) * LDK + q2 * 16 + g4 * 4]);
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c5 = 0; c5 < 5; ++c5)
-                  acc3[c5] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c5][r], vf[r], acc3[c5], 0, 0, 0);
-            }
-            lds_barrier();
-          }
-          const long long pxp = rowpix[h * HR + wid * 16 + li16];
-          if (pxp >= 0) {
-#pragma unroll
-            for (int c5 = 0; c5 < 5; ++c5)
-              *reinterpret_cast<f32x4v*>(a.post_p + (size_t)pxp * 80 + c5 * 16 + 4 * g4) = acc3[c5];
-          }
-        }
-      }
 #pragma unroll
       for (int tn = 0; tn < PTN; ++tn)
 #pragma unroll
@@ -1170,19 +926,9 @@ __global__ __launch_bounds__(WM * WN * 64 + (POST == 5 ? 64 : 0), (X3 && (TN >= 
   // output rows (coalesced float4 stores and aux loads instead of 4-byte column scatters).
   const int epi = a.ksplit > 1 ? -1 : a.epi;      // split-K: raw partial sums, epilogue in the reduce
   float* const outp = a.ksplit > 1 ? a.part + (size_t)split * a.slab : a.out;
-  // (laboratory build only: the in-launch slab sum is correct -- bit-equal to the reduce launches at seven shapes -- and SLOWER:
-  //  +85 us per iteration at cfg 2 with every split fused, +0..10 us with only the <= 8-slab launches; DESIGN_EXPERIMENTS.md A.10)
-#ifdef SGA_EXPERIMENTS
-  const bool fuse_reduce = a.ksplit > 1 && a.tickets != nullptr;
-  const __amdgpu_buffer_rsrc_t part_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, 0x7ffffff0, 0x00020000);
-#endif
-  float* Cs = smem + (LOWF ? (wid & 1) : wid) * (32 * CPITCH);
+  float* Cs = smem + wid * (32 * CPITCH);
   constexpr int F4_PER_ROW = TN * 8;
   constexpr int F4_ITERS = (32 * F4_PER_ROW) / 64;
-  constexpr int EPI_ROUNDS = LOWF ? WM * WN / 2 : 1;      // low-footprint form: two waves stage at a time
-#pragma unroll
-  for (int round = 0; round < EPI_ROUNDS; ++round) {
-  if (!LOWF || (wid >> 1) == round) {
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -1235,71 +981,10 @@ __global__ __launch_bounds__(WM * WN * 64 + (POST == 5 ? 64 : 0), (X3 && (TN >= 
         default:
           break;
       }
-#ifdef SGA_EXPERIMENTS
-      if (fuse_reduce) {
-        // write-through (sc1): the slab must be visible to a workgroup on another XCD without a release fence that would
-        // write back the whole L2 (MI355X_MICROARCH.md, publish-large: 3.0 against 8.2 us per 64 KB)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), part_rsrc,
-                                               (int)((((size_t)split * (size_t)a.slab) + o) * sizeof(float)), 0, 16);
-      } else
-#endif
-      {
-        *reinterpret_cast<f32x4*>(outp + o) = v;
-      }
+      *reinterpret_cast<f32x4*>(outp + o) = v;
     }
     __builtin_amdgcn_wave_barrier();
   }
-  }
-  if constexpr (LOWF) __syncthreads();
-  }
-#ifdef SGA_EXPERIMENTS
-  if (fuse_reduce) {
-    // ---- ticket: the last workgroup of this output tile sums its slabs (fixed order) and applies the epilogue ----------
-    __shared__ __attribute__((aligned(16))) int sk_last[4];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains its write-through stores
-    __syncthreads();
-    if (tid == 0) {
-      unsigned* const tk = a.tickets + (size_t)phase * a.tiles_per_phase * a.ntiles_n + (size_t)mt * a.ntiles_n + nt;
-      const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = t == (unsigned)(nsplit - 1);
-      if (last) {
-        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // this CU's L1 may hold the previous iteration's slabs
-      }
-      sk_last[0] = last;
-    }
-    __syncthreads();
-    if (sk_last[0]) {
-      constexpr int F4R = BN / 4;
-      for (int f = tid; f < BM * F4R; f += NT) {
-        const int row = f / F4R, c4 = f - row * F4R;
-        const long long px = rowpix[row];
-        const int n = n0 + c4 * 4;
-        if (px < 0 || n >= a.Cout) continue;
-        const size_t o = (size_t)px * a.out_cs + a.out_coff + n;
-        f32x4 sum = ld4(a.part + o);
-        for (int s0 = 1; s0 < nsplit; s0 += 8) {                  // loads 8 at a time, adds in the order 1, 2, ... (= splitk_reduce_kernel)
-          f32x4 v8[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v8[k] = ld4(a.part + (size_t)(s0 + k < nsplit ? s0 + k : nsplit - 1) * a.slab + o);
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (s0 + k < nsplit) sum += v8[k];
-        }
-        if ((a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU) && a.bias) sum += ld4(a.bias + n);
-        if (a.epi == EPI_BIAS_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sum[e] = fmaxf(sum[e], 0.f);
-        } else if (a.epi == EPI_RELU_MASK) {
-          const f32x4 mk = ld4(a.aux0 + o);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sum[e] = mk[e] > 0.f ? sum[e] : 0.f;
-        }
-        *reinterpret_cast<f32x4*>(a.out + o) = sum;
-      }
-    }
-  }
-#endif
   SGA_PROBE_END();
 }
 
@@ -1364,12 +1049,10 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr bool GLDS = glds_instance(TM, TN, WM, WN, PRO, SMALLC, X3, POST);
-  constexpr bool LOWF = POST == 3;
-  constexpr int GSTAGES = POST == 4 ? 4 : (LOWF ? 1 : 2);
   constexpr int MAIN_FLOATS = X3 ? x3_main_floats(BM, BN, x3_pipelined(PRO, SMALLC, X3))
-                                 : (GLDS ? GSTAGES * (BM + BN) * 32 : (BM + BN) * LDK);
-  constexpr int EPI_FLOATS = (LOWF ? 2 : WM * WN) * 32 * (TN * 32 + 4);
-  constexpr int POST_FLOATS = (POST == 1 || POST == 2) ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
+                                 : (GLDS ? 2 * (BM + BN) * 32 : (BM + BN) * LDK);
+  constexpr int EPI_FLOATS = WM * WN * 32 * (TN * 32 + 4);
+  constexpr int POST_FLOATS = POST == 1 ? (post_rows(BM, BN) * (BN + 4) + post_qbufs(BM) * BN * LDK) : 0;
   constexpr int F0 = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
   const size_t lds = (size_t)(F0 > POST_FLOATS ? F0 : POST_FLOATS) * sizeof(float) + BM * sizeof(long long);
   // once per (instance, device): a process may drive several GPUs, and handles may live on several threads
@@ -1388,8 +1071,7 @@ int launch_inst(const ConvArgs& a, hipStream_t stream) {
     for (int p = 0; p < a.nphase; ++p) grid += a.tiles_per_phase * a.ntiles_n * a.nsplit[p];
   }
   if (grid <= 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC, X3, POST>), dim3(grid), dim3(NT + (POST == 5 ? 64 : 0)), lds,
-                     stream, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, PRO, SMALLC, X3, POST>), dim3(grid), dim3(NT), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1443,14 +1125,13 @@ void conv_kernel_name(const ConvArgs& a, char* out, int len) {
     case 32: tn = 1; tm = 1; wm = 4; wn = 1; break;
   }
   if (a.bm == 256) wm = 4;
-  if (a.bm == 256 && a.x3 && a.x3w4 && !a.post) { wm = 2; tm = 4; }
   if (a.bm == 64) tm = 1;
   // the symbol as rocprofv3 prints it, spaces removed (profiles/*_kernel_stats.csv, *_pmc_traffic.json); the 7th argument is the
   // precision: 0 = f32 MFMA, 1 = bf16x3, 2 = bf16x2
   snprintf(out, len, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%d,%d>", tm, tn, wm, wn, a.smallc ? 0 : a.pro,
            a.smallc ? "true" : "false",
            (a.x3 && !a.smallc && bn != 32) ? ((a.x3 == 2 && a.pro == PRO_NONE) ? 2 : 1) : 0,
-           a.post ? (a.post_p ? 2 : 1) : (a.lowfoot && a.bm == 64 && bn == 192 ? 3 : (a.deep && a.bm == 64 && bn == 192 && !a.x3 ? 3 + a.deep : 0)));
+           a.post ? 1 : 0);
 }
 
 int launch_splitk_reduce(const ConvArgs& a, long long n, hipStream_t stream) {
@@ -1476,17 +1157,12 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
       if (a.bm == 64) {
         if (a.smallc || a.pro != PRO_NONE) return (int)hipErrorInvalidValue;
         if (a.post) {
-          if (a.ksplit > 1 || a.epi != EPI_BIAS || a.Cout != 192 || a.out_coff != 0 || a.out_cs != 192 || a.post_p)
+          if (a.ksplit > 1 || a.epi != EPI_BIAS || a.Cout != 192 || a.out_coff != 0 || a.out_cs != 192)
             return (int)hipErrorInvalidValue;
           if (a.x3) return launch_xp<1, 3, 2, 2, 1>(a, stream);
           return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 1>(a, stream);
         }
         if (a.x3) return launch_xp<1, 3, 2, 2>(a, stream);
-#ifdef SGA_EXPERIMENTS
-        if (a.lowfoot) return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 3>(a, stream);
-        if (a.deep == 1) return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 4>(a, stream);
-        if (a.deep == 2) return launch_inst<1, 3, 2, 2, PRO_NONE, false, false, 5>(a, stream);
-#endif
         return launch_inst<1, 3, 2, 2, PRO_NONE, false>(a, stream);
       }
       if (a.bm == 256) {
@@ -1494,17 +1170,9 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
         if (a.post) {
           if (a.ksplit > 1 || a.epi != EPI_BIAS || a.Cout != 192 || a.out_coff != 0 || a.out_cs != 192)
             return (int)hipErrorInvalidValue;
-          if (a.x3) return a.post_p ? (int)hipErrorInvalidValue : launch_xp<2, 3, 4, 2, 1>(a, stream);
-#ifdef SGA_EXPERIMENTS
-          if (a.post_p) return launch_inst<2, 3, 4, 2, PRO_NONE, false, false, 2>(a, stream);
-#else
-          if (a.post_p) return (int)hipErrorInvalidValue;
-#endif
+          if (a.x3) return launch_xp<2, 3, 4, 2, 1>(a, stream);
           return launch_inst<2, 3, 4, 2, PRO_NONE, false, false, 1>(a, stream);
         }
-#ifdef SGA_EXPERIMENTS      // (one wave per SIMD, 128 x 96 per wave: gs2.bwd 343 us against 302 for the 8-wave instance; A.9)
-        if (a.x3 && a.x3w4) return launch_inst<4, 3, 2, 2, PRO_NONE, false, 1>(a, stream);
-#endif
         if (a.x3) return launch_xp<2, 3, 4, 2>(a, stream);
         return launch_inst<2, 3, 4, 2, PRO_NONE, false>(a, stream);
       }

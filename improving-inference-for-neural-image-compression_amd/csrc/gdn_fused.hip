@@ -499,20 +499,7 @@ int gdn_tile_rows(int C, long long M, int pro) {
   return wm * 32;
 }
 
-// the persistent wave-specialised kernel (igdn_bwd_ws.hip) takes igdn2.bwd-shaped launches: backward with the gradient
-// convolution in it, f32 contraction, and enough tiles for its pipeline (>= 2 per CU)
-static bool use_ws(const GdnArgs& a) {
-#ifdef SGA_EXPERIMENTS      // laboratory build only (it lost in the iteration: DESIGN_EXPERIMENTS.md A.10); scripts/r05/igdn_ws_bench.hip defines it too
-  if (!a.ws || !igdn_bwd_ws_supported(a)) return false;
-  return a.ws == 2 || (a.M + 63) / 64 >= 512;
-#else
-  (void)a;
-  return false;
-#endif
-}
-
 void gdn_kernel_name(const GdnArgs& a, char* out, int len) {
-  if (use_ws(a)) { snprintf(out, len, "igdn_bwd_ws_kernel<%d>", a.C / 32); return; }
   int wm, wn;
   pick_shape(a.C, a.M, a.pro == GDN_PRO_CONV3, wm, wn);
   // the symbol as rocprofv3 prints it, spaces removed (profiles/*_kernel_stats.csv, *_pmc_traffic.json)
@@ -520,9 +507,6 @@ void gdn_kernel_name(const GdnArgs& a, char* out, int len) {
 }
 
 int launch_gdn_tile(const GdnArgs& a, hipStream_t s) {
-#ifdef SGA_EXPERIMENTS
-  if (use_ws(a)) return launch_igdn_bwd_ws(a, s);
-#endif
   int wm, wn;
   pick_shape(a.C, a.M, a.pro == GDN_PRO_CONV3, wm, wn);
   switch (a.C / 32) {

@@ -20,7 +20,6 @@ constexpr int BM_TILE = 128;
 struct PackedConv {
   float* w = nullptr;   // device [nslab][Npad][Kc]
   unsigned short* w3 = nullptr;   // device bf16x3 planes [nslab][Npad][Kc/32][3][32] (precision mode bf16x3)
-  float* wf = nullptr;  // the same matrix in MFMA fragment order (pack_frag): B operands loaded straight into registers
   int Kc = 0;           // contiguous K per slab row (C_in of the GEMM)
   int N = 0;            // real output channels
   int Npad = 0, bn = 0;
@@ -85,30 +84,12 @@ struct sga_handle {
   struct ClkSlot { char name[96]; int grid; };
   std::vector<ClkSlot> clk_slots;
   unsigned* ticket = nullptr;      // k_step_boundary's last-workgroup counter (zero between launches)
-  // split-K slab sums inside the convolution launch (conv_mfma.hip, ConvArgs::tickets): one zeroed counter per output tile, a
-  // set per concurrently running branch.  fuse_reduce: bit 0 = main chain, bit 1 = hyper branch (SGA_FUSE_REDUCE, laboratory)
-  unsigned* sk_tickets[2] = {nullptr, nullptr};
-  static constexpr int kTickets = 8192;
-  int deep64 = 0;                  // SGA_DEEP64 (laboratory): bit 0 = main chain, bit 1 = hyper branch: under-filled 64-row launches on the four-stage
-                                   //   instance (conv_mfma.hip POST = 4), split so that one workgroup lands on every CU
-  int deep64_target = 256;         // SGA_DEEP64_TARGET: workgroups such a launch is split into
-  int deep64_kind = 1;             // SGA_DEEP64_KIND: 1 = four-stage instance (POST = 4), 2 = loader-wave instance (POST = 5: every 64-row launch
-                                   //   without a post-phase, default split: bit-identical to the plain instance)
-  int fuse_reduce = 0;             // (off: correct and slower, DESIGN_EXPERIMENTS.md A.10)
-  unsigned* ws_sched = nullptr;    // igdn_bwd_ws_kernel's shared tile counter + exit counter (zero between launches)
-  int igdn_ws = 0;                 // SGA_IGDN_WS (laboratory build): 0 = igdn2.bwd on gdn_tile_kernel (default), 1 = on the persistent wave-specialised kernel of
-                                   //   igdn_bwd_ws.hip when the launch has >= 2 tiles per CU, 2 = whenever its shape is supported (tests).
-                                   //   Round 5: alone 144.5 against 148.3 us at cfg 2, but +20 us in the iteration -- its one 150-KB workgroup per
-                                   //   CU leaves no room for the hyper branch's kernels beside it (DESIGN_EXPERIMENTS.md A.10)
-  bool igdn_ws_dynamic = true;     // SGA_IGDN_WS_SCHED=static: tiles b, b + grid, ... instead of the shared counter
   bool fused_boundary = true;      // SGA_FUSED_BOUNDARY=0: Adam, relaxation and finalize as three launches
   float* gs3_halo_w = nullptr;   // C->3 layer packed for deconv3.hip: [C/32][9][16][32]
   bool gs3_generic = false;      // SGA_GS3_GENERIC=1: use the generic gather-GEMM for the C->3 layer
   float* gs3_w80 = nullptr;      // the same layer for deconv3_gemm.hip: [80][C], row (ky*5+kx)*3 + c
   Buf p3;                        // its product matrix P [B * 8yh * 8yw][80]
   bool gs3_gemm = false;         // SGA_GS3_GEMM=1: GEMM + col2im (deconv3_gemm.hip) instead of the halo-tiled kernel (deconv3.hip)
-  bool post_p = false;           // SGA_POST_P=1 (experiment): the C -> 3 layer's products formed in the post-phase of gs2.fwd when that
-                                 //   launch fuses the IGDN (C = 192); the layer is then only the col2im kernel.  Measured: no gain.
   std::vector<void*> owned;      // every hipMalloc'd block
 
   // ---- workspace ----
@@ -197,7 +178,6 @@ struct sga_handle {
   Geom geom_zeroed;              // geometry for which xpad/gpad borders are known zero
   bool borders_valid = false;
 
-  bool side_lowfoot = false;       // SGA_SIDE_LOWFOOT=1: the hyper branch's 64-row launches in the 33-KB form (fit beside gs2.bwd)
   int fork_delay_us = 0;           // SGA_FORK_DELAY_US (experiment)
   bool in_hyper = false;           // the launches being enqueued belong to the hyper branch
   int side_target = 384;           // split-K target (workgroups per launch) of the hyper branch (SGA_SIDE_TARGET; 0: the main chain's 512)
@@ -310,8 +290,7 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   // lose with that target and keep 512; profiles/r04_b1_split_targets_by_layer.txt)
   static const int small_tiles = LAB_ENV("SGA_SMALL_TILES") ? atoi(LAB_ENV("SGA_SMALL_TILES")) : 64;      // 0: rule off (experiments)
   if (a.bm != 256 && blocks <= small_tiles) target = 256;
-  if (a.deep == 1) target = h->deep64_target;
-  else if (h->in_hyper && h->side_target > 0) target = h->side_target;   // hyper branch (whichever stream it runs on: the
+  if (h->in_hyper && h->side_target > 0) target = h->side_target;   // hyper branch (whichever stream it runs on: the
                                                                      // split decides the summation order, i.e. result bits)
   const int bn = a.Npad / a.ntiles_n;
   const bool big = blocks > 256 || (blocks == 256 && a.nphase == 1 && !h->split256);
@@ -369,8 +348,6 @@ struct PostGdn {
   const float* gamma_w = nullptr; const float* beta = nullptr; float* s_out = nullptr; float* v_out = nullptr;
   const unsigned short* gamma_w3 = nullptr;      // the same gamma pre-split into bf16 planes (bf16x3 post-phase)
   bool drop_u = false;       // in: the fused launch need not write u (the backward pass uses v / s)
-  const float* w3 = nullptr; float* p3 = nullptr;      // in (optional): also form the next (C -> 3) layer's products P = v . w3
-  bool p3_done = false;      // out: the fused launch wrote P
   bool fused = false;        // out: the convolution launch did the IGDN as well
 };
 
@@ -442,20 +419,10 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
       a.tiles_per_phase = (int)cdiv(rows, 256);
     }
   }
-  a.deep = 0;
-#ifdef SGA_EXPERIMENTS
-  {
-    const long long blocks0 = (long long)a.nphase * a.tiles_per_phase * a.ntiles_n;
-    if ((h->deep64 & (h->in_hyper ? 2 : 1)) && a.bm == 64 && (blocks0 <= 256 || h->deep64_kind == 2) && !h->x3 && !a.smallc &&
-        a.pro == PRO_NONE && a.Npad / a.ntiles_n == 192)
-      a.deep = h->deep64_kind;
-  }
-#endif
   a.ksplit = pick_ksplit(h, a);
   a.zeros = h->zeros;
   a.prio = (h->cur_part == &h->partB) ? h->side_wave_prio : h->main_wave_prio;
   a.side = h->in_hyper ? 1 : 0;
-  a.lowfoot = (h->in_hyper && h->side_lowfoot && a.bm == 64 && !a.post && !a.smallc && a.pro == PRO_NONE && !h->x3) ? 1 : 0;
 #ifdef SGA_CLOCK_PROBE
   a.clk = (h->clk_mode == 1 && h->profiling && h->profile_by_layer) ? h->clk_probe : nullptr;
   if (h->clk_mode == 2 && h->clk_slots.size() < 40) {
@@ -484,11 +451,6 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
     if (post->fused) {
       a.post = 1; a.post_w = post->gamma_w; a.post_wx3 = post->gamma_w3; a.post_beta = post->beta; a.post_s = post->s_out; a.post_v = post->v_out;
       if (post->drop_u) a.out = nullptr;
-      if (post->w3 && post->p3 && a.Cout == 192 && a.bm == 256) {
-        a.post_w3 = post->w3; a.post_p = post->p3;
-        post->p3_done = true;
-        a.flops += 2.0 * a.B * a.Hout * a.Wout * 75.0 * a.Cout;      // the C -> 3 layer's useful MACs ride in this launch
-      }
       a.flops += 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cout;
     }
   }
@@ -501,24 +463,8 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
   { // laboratory (A.8): bf16x3 arithmetic in only one of the two branches, to isolate the two-stream nondeterminism
     static const int only = LAB_ENV("SGA_X3_ONLY") ? atoi(LAB_ENV("SGA_X3_ONLY")) : 0;      // 1: main chain only, 2: hyper branch only
     if ((only == 1 && h->in_hyper) || (only == 2 && !h->in_hyper)) a.x3 = 0; }
-  { static const bool w4 = LAB_ENV("SGA_X3_W4") != nullptr && LAB_ENV("SGA_X3_W4")[0] == '1';
-    a.x3w4 = (w4 && a.x3 == 1 && a.bm == 256 && !a.post) ? 1 : 0; }
   const long long n_out = (long long)a.B * a.Hout * a.Wout * a.Cout;
   if (a.ksplit > 1) { a.part = h->cur_part->p; a.slab = n_out; }
-  // the slab sum inside the launch (last arriver of every output tile) instead of a reduce launch, where nothing else consumes
-  // the slabs: removes the six reduce launches of the hyper branch and the one after gs0.bwd (round 5)
-  a.tickets = nullptr;
-#ifdef SGA_EXPERIMENTS
-  if (a.ksplit > 1 && !defer) {
-    const int which = (h->cur_part == &h->partB) ? 1 : 0;
-    const long long tiles_all = (long long)a.nphase * a.tiles_per_phase * a.ntiles_n;
-    const bool ok = (h->fuse_reduce >> which) & 1;
-    static const int max_s = LAB_ENV("SGA_FUSE_REDUCE_MAXS") ? atoi(LAB_ENV("SGA_FUSE_REDUCE_MAXS")) : 8;      // the last arriver sums ALONE
-    if (ok && a.ksplit <= max_s && h->sk_tickets[which] && tiles_all <= sga_handle::kTickets && (long long)a.ksplit * n_out * 4 < 0x7ffffff0LL &&
-        (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RELU_MASK))
-      a.tickets = h->sk_tickets[which];
-  }
-#endif
   bool gprof_here = false;
   if (h->gprof && !h->gprof_in_graph) {
     hipStreamCaptureStatus gcs = hipStreamCaptureStatusNone;
@@ -585,7 +531,7 @@ int conv_launch(sga_handle* h, ConvArgs& a, hipStream_t st, Deferred* defer = nu
       if (a.s_out != 2) for (int p = 1; p < 4; ++p) defer->nsplit[p] = defer->nsplit[0];
     }
   }
-  if (a.ksplit > 1 && !defer && !a.tickets) HIPCHK(h, launch_splitk_reduce(a, n_out, st));
+  if (a.ksplit > 1 && !defer) HIPCHK(h, launch_splitk_reduce(a, n_out, st));
   if (h->profiling && h->profile_by_layer) {    // layer-level stats: conv + its reduce
     HIPCHK(h, hipEventRecord(r.b, st));
     h->prof.push_back(r);
@@ -673,24 +619,6 @@ bool bn96_as_192(const sga_handle* h) {
   return (!h->x3 || h->x3_variants) && !(e && e[0] == '0');
 }
 
-// B operand in MFMA fragment order.  `w` is [nslab][Npad][Kc] (rows = output channels, K contiguous); step Q = slab * (Kc / 8)
-// + q covers k = q*8 .. q*8+7 of its slab; lane (half = lane >> 5, col = lane & 31) of the 32x32x2 MFMA numbered r (0..3) of
-// that step multiplies row nb*32 + col at k = q*8 + half*4 + r -- so one wave-load of 16 bytes per lane is 1 KB contiguous:
-//   f[((Q * NB + nb) * 64 + lane) * 4 + r] = w[(slab * Npad + nb*32 + col) * Kc + q*8 + half*4 + r],  NB = N / 32
-int pack_frag(sga_handle* h, PackedConv& pc, const std::vector<float>& w) {
-  if (pc.N % 32 != 0 || pc.Kc % 8 != 0) return SGA_OK;
-  const int NB = pc.N / 32, qs = pc.Kc / 8;
-  std::vector<float> f((size_t)pc.nslab * qs * NB * 256, 0.f);
-  for (int sl = 0; sl < pc.nslab; ++sl)
-    for (int q = 0; q < qs; ++q)
-      for (int nb = 0; nb < NB; ++nb)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int r = 0; r < 4; ++r)
-            f[((((size_t)sl * qs + q) * NB + nb) * 64 + lane) * 4 + r] =
-                w[((size_t)sl * pc.Npad + nb * 32 + (lane & 31)) * pc.Kc + q * 8 + (lane >> 5) * 4 + r];
-  return upload(h, &pc.wf, f.data(), f.size());
-}
-
 // GEMM with N = co, K = ci:  w[t][co][ci] = K[t][ci][co]   (forward of any conv)
 int pack_fwd(sga_handle* h, PackedConv& pc, const float* K, int taps, int ci, int co, int epi) {
   pc.Kc = ci; pc.N = co; pc.nslab = taps;
@@ -730,9 +658,6 @@ int pack_gdn(sga_handle* h, PackedConv& pc, const float* gamma, int C, bool back
   for (int i = 0; i < C; ++i)
     for (int k = 0; k < C; ++k)
       w[(size_t)i * C + k] = backward ? gamma[(size_t)i * C + k] : gamma[(size_t)k * C + i];
-#ifdef SGA_EXPERIMENTS
-  if (backward) SGACHK(pack_frag(h, pc, w));      // igdn_bwd_ws.hip (laboratory build)
-#endif
   return upload_packed(h, pc, w);
 }
 
@@ -780,9 +705,6 @@ int pack_smallc(sga_handle* h, PackedConv& pc, const float* K, int C, bool bwd) 
         }
       }
     }
-#ifdef SGA_EXPERIMENTS
-  if (bwd) SGACHK(pack_frag(h, pc, w));           // igdn_bwd_ws.hip (laboratory build)
-#endif
   return upload_packed(h, pc, w, false);
 }
 
@@ -988,8 +910,6 @@ int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float*
     gdn_source(g, g_v, d);
     if (gpad) {
       g.pad = gpad; g.wc = pc3->w; g.Hg = Hh; g.Wg = Ww; g.Hp = Hp; g.Wp = Wp;
-      // the persistent wave-specialised kernel (igdn_bwd_ws.hip; f32 contraction in every precision mode)
-      g.wf = pc.wf; g.wcf = pc3->wf; g.ws = h->igdn_ws; g.sched = h->igdn_ws_dynamic ? h->ws_sched : nullptr;
     }
     g.w = pc.w; g.wx3 = pc.w3; g.x3 = (h->x3 && h->x3_variants) ? 1 : 0; g.u = u; g.s = s; g.out = g_u; g.v = v;
     g.flops = 2.0 * B * Hh * Ww * (double)pc.Kc * pc.N + (gpad ? 2.0 * B * Hh * Ww * 75.0 * pc.N : 0.0);
@@ -1010,15 +930,13 @@ int igdn_bwd(sga_handle* h, const PackedConv& pc, const float* g_v, const float*
 // kernel is in use; otherwise the caller launches k_mse
 int deconv_to3(sga_handle* h, const PackedConv& pc, const float* bias, const float* in, int B,
                int Hi, int Wi, int Ho, int Wo, float* out, hipStream_t st, const float* mse_x = nullptr,
-               int Hp = 0, int Wp = 0, bool* mse_done = nullptr, bool p_ready = false) {
-  const bool gemm = p_ready || (h->gs3_gemm && !h->gs3_generic && pc.Kc % 64 == 0 && pc.Kc <= 384 &&
-                                (size_t)B * Hi * Wi * 80 <= h->p3.cap);
+               int Hp = 0, int Wp = 0, bool* mse_done = nullptr) {
+  const bool gemm = h->gs3_gemm && !h->gs3_generic && pc.Kc % 64 == 0 && pc.Kc <= 384 && (size_t)B * Hi * Wi * 80 <= h->p3.cap;
   if (!h->gs3_generic) {
     sga_handle::ProfRec r;
     if (h->profiling) {
       r.flops = 2.0 * B * Hi * Wi * 25.0 * pc.Kc * 3.0;
-      const char* kn = p_ready ? "deconv3_col2im" : (gemm ? "deconv3_gemm+col2im" : "deconv3_halo_kernel");
-      if (p_ready) r.flops = 0.0;      // counted in the launch that formed P
+      const char* kn = gemm ? "deconv3_gemm+col2im" : "deconv3_halo_kernel";
       if (h->profile_by_layer) snprintf(r.name, sizeof(r.name), "%s %s", h->cur_tag, kn);
       else snprintf(r.name, sizeof(r.name), "%s", kn);
       HIPCHK(h, hipEventCreate(&r.a));
@@ -1027,7 +945,7 @@ int deconv_to3(sga_handle* h, const PackedConv& pc, const float* bias, const flo
     }
     if (gemm) {
       const bool fuse = mse_x && h->fused_mse;
-      if (!p_ready) HIPCHK(h, launch_deconv3_gemm(in, h->gs3_w80, h->p3.p, B, Hi, Wi, pc.Kc, st));
+      HIPCHK(h, launch_deconv3_gemm(in, h->gs3_w80, h->p3.p, B, Hi, Wi, pc.Kc, st));
       HIPCHK(h, launch_deconv3_col2im(h->p3.p, bias, out, B, Hi, Wi, Ho, Wo, fuse ? mse_x : nullptr, h->ctx, h->sums,
                                       h->gpad.p, Hp, Wp, st));
       if (fuse) *mse_done = true;
@@ -1194,7 +1112,6 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   // Layers whose tile grid under-fills the chip run split-K; their partial slabs are summed (+ bias)
   // by the IGDN kernel that follows instead of by a reduce launch (fused_gdn).
   const bool fz = h->fused_gdn;
-  bool p3_done = false;      // the C -> 3 layer's products were formed by gs2.fwd's post-phase
   // u is needed again only by the IGDN data-gradient, which can form it as v / s: with the tile kernels in use the
   // forward pass stores s and v only (gs2.fwd + IGDN writes 201 instead of 302 MB at cfg 2)
   const bool drop_u = fz && with_grad && !h->keep_u;
@@ -1203,16 +1120,11 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
     PostGdn pg;
     pg.gamma_w = h->gs_gdn_f[L].w; pg.gamma_w3 = h->gs_gdn_f[L].w3; pg.beta = h->gs_beta[L]; pg.s_out = h->s[L].p; pg.v_out = h->v[L].p;
     pg.drop_u = drop_u;
-    if (L == 2 && h->post_p && !h->gs3_generic && (size_t)B * (2 * hh) * (2 * ww) * 80 <= h->p3.cap) {
-      pg.w3 = h->gs3_w80; pg.p3 = h->p3.p;
-    }
-    p3_done = false;
     SGACHK(tick(kFwd[L]));
     h->cur_tag = kFwd[L];
     SGACHK(deconv_fwd(h, h->gs_f[L], h->gs_bias[L], cur, B, hh, ww, h->u[L].p, EPI_BIAS, st, fz ? &d : nullptr,
                       fz ? &pg : nullptr));
     hh *= 2; ww *= 2;
-    p3_done = pg.p3_done;
     if (!pg.fused) {           // otherwise the IGDN ran as the post-phase of the convolution launch
       SGACHK(tick());
       h->cur_tag = kIgdn[L];
@@ -1224,7 +1136,7 @@ int synth_branch(sga_handle* h, const Geom& g, const float* x, bool with_grad, h
   h->cur_tag = "gs3.fwd";
   bool mse_done = false;     // step: the distortion sums and the gradient image come out of gs3.fwd's epilogue
   SGACHK(deconv_to3(h, h->gs_f[3], h->gs_bias[3], cur, B, hh, ww, g.H, g.W, h->xt.p, st, with_grad ? x : nullptr,
-                    g.Hp, g.Wp, &mse_done, p3_done));
+                    g.Hp, g.Wp, &mse_done));
   if (!mse_done) {
     SGACHK(tick());
     HIPCHK(h, launch_mse(x, h->xt.p, with_grad ? h->ctx : nullptr, B, g.H, g.W, g.Hp, g.Wp, h->sums,
@@ -1434,12 +1346,13 @@ sga_handle::GraphEntry* find_graph(sga_handle* h, const sga_handle::GraphKey& k)
   return nullptr;
 }
 
-// the fork point a TIMED graph of this geometry was built with (any relaxation / bound / kind: the point depends on the
-// launch durations, which these do not change), or null
-const char* tuned_fork_for(const sga_handle* h, int B, int H, int W, bool* found) {
+// the fork point a TIMED graph of this geometry AND KIND was built with (any relaxation / bound: the point depends on the launch
+// durations, which these do not change; the bits-back stage-1 step has other launches in its hyper branch -- the density, the
+// posterior terms -- so its point is never taken from an SGA graph or the other way round), or null
+const char* tuned_fork_for(const sga_handle* h, int kind, int B, int H, int W, bool* found) {
   *found = false;
   for (const auto& e : h->graphs)
-    if (e.tuned && e.key.B == B && e.key.H == H && e.key.W == W) { *found = true; return e.fork_name; }
+    if (e.tuned && e.key.kind == kind && e.key.B == B && e.key.H == H && e.key.W == W) { *found = true; return e.fork_name; }
   return nullptr;
 }
 
@@ -1626,8 +1539,6 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
       // the iteration is 30 us shorter (joint sweep, DESIGN_EXPERIMENTS.md A.7); SGA_GS3_GEMM=0 selects the halo kernel.
       const char* eg = LAB_ENV("SGA_GS3_GEMM");
       h->gs3_gemm = !(eg && eg[0] == '0');
-      eg = LAB_ENV("SGA_POST_P");
-      h->post_p = eg && eg[0] == '1';
     }
     const char* e3 = LAB_ENV("SGA_GS3_GENERIC");
     h->gs3_generic = e3 && e3[0] == '1';
@@ -1724,14 +1635,6 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     TRY(dev_alloc(h, &p, 17 * 128));      // k_step_boundary: top counter + 16 group counters, one cache line each
     if (hipMemset(p, 0, 17 * 128) != hipSuccess) return fail(SGA_ERR_HIP);
     h->ticket = (unsigned*)p;
-    TRY(dev_alloc(h, &p, 256));
-    if (hipMemset(p, 0, 256) != hipSuccess) return fail(SGA_ERR_HIP);
-    h->ws_sched = (unsigned*)p;
-    for (int k = 0; k < 2; ++k) {
-      TRY(dev_alloc(h, &p, sizeof(unsigned) * sga_handle::kTickets));
-      if (hipMemset(p, 0, sizeof(unsigned) * sga_handle::kTickets) != hipSuccess) return fail(SGA_ERR_HIP);
-      h->sk_tickets[k] = (unsigned*)p;
-    }
   }
   {
     void* p = nullptr;
@@ -1852,8 +1755,6 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->keep_u = env && env[0] == '1';
   env = LAB_ENV("SGA_FORK_DELAY_US");
   if (env) h->fork_delay_us = atoi(env);
-  env = LAB_ENV("SGA_SIDE_LOWFOOT");
-  h->side_lowfoot = env && env[0] == '1';
   env = LAB_ENV("SGA_MAIN_WAVE_PRIO");
   if (env) { h->main_wave_prio = atoi(env); g_deconv3_prio = h->main_wave_prio; }
   env = LAB_ENV("SGA_SIDE_WAVE_PRIO");
@@ -1870,18 +1771,6 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   h->fused_mse = !(env && env[0] == '0');
   env = getenv("SGA_NO_SPLITK");
   h->no_splitk = env && env[0] == '1';
-  env = LAB_ENV("SGA_DEEP64");
-  if (env) h->deep64 = atoi(env);
-  env = LAB_ENV("SGA_DEEP64_KIND");
-  if (env) h->deep64_kind = atoi(env);
-  env = LAB_ENV("SGA_DEEP64_TARGET");
-  if (env) h->deep64_target = atoi(env);
-  env = LAB_ENV("SGA_FUSE_REDUCE");
-  if (env) h->fuse_reduce = atoi(env);
-  env = LAB_ENV("SGA_IGDN_WS");
-  if (env) h->igdn_ws = atoi(env);
-  env = LAB_ENV("SGA_IGDN_WS_SCHED");
-  if (env) h->igdn_ws_dynamic = strcmp(env, "static") != 0;
   env = getenv("SGA_PROFILE_BY_LAYER");
   h->profile_by_layer = env && env[0] == '1';
 #undef TRY
@@ -2072,6 +1961,9 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
   const Geom g = make_geom(B, H, W);
   const int C = h->C;
   const int64_t ny = (int64_t)B * g.yh * g.yw * C, nz = (int64_t)B * g.zh * g.zw * C;
+  // a one-shot call at ANOTHER size between two calls of an open run (sga_base_compress, sga_eval) leaves the zero borders of the
+  // gradient image valid for its geometry, not this one: re-check (one compare when nothing changed)
+  SGACHK(ensure_borders(h, g, st));
   // other entry points (sga_step_grads, sga_eval) may have used the step context and the sums
   // the step context of the first of these iterations; k_finalize_step advances it from then on
   HIPCHK(h, launch_set_ctx(h->ctx, h->run_it, its, h->hT[h->run_it], h->hLr[h->run_it], h->run_lambda,
@@ -2197,7 +2089,7 @@ int sga_run_steps(sga_handle* h, int n, void* stream) {
       hipGraphExec_t ex = nullptr;
       bool tuned = false;
       if (!tune) {
-        if (h->fork_auto) h->fork_name = tuned_fork_for(h, B, H, W, &tuned);
+        if (h->fork_auto) h->fork_name = tuned_fork_for(h, 0, B, H, W, &tuned);
         ex = capture();
       } else {
         SGACHK(timed_fork_choice(h, st, B, H, W, capture, &ex, &tuned_done));
@@ -2491,7 +2383,7 @@ int sga_op_rate_terms(sga_handle* h, const float* y_tilde, const float* z_tilde,
   return SGA_OK;
 }
 
-// The bound is a launch argument of k_gaussian, i.e. part of every captured step graph: drop them.
+// The bound is a launch argument of k_gaussian, i.e. baked into a captured step graph: it is part of the graph cache's KEY.
 int sga_set_scale_bound(sga_handle* h, float scale_bound) {
   if (!h || !(scale_bound >= 0.f) || !(scale_bound < 1e30f)) return SGA_ERR_BAD_ARG;
   // the bound is part of the graph cache's key: the graphs captured under the other value stay cached, nothing is synchronised
@@ -2691,7 +2583,7 @@ int bb_iterations(sga_handle* h, int stage, const Geom& g, int n, hipStream_t st
         SGACHK(timed_fork_choice(h, st, g.B, g.H, g.W, capture, &ex, &done));
         tuned = ex != nullptr;
       } else if (stage == 0 && h->fork_auto) {
-        h->fork_name = tuned_fork_for(h, g.B, g.H, g.W, &tuned);
+        h->fork_name = tuned_fork_for(h, 1, g.B, g.H, g.W, &tuned);
       }
       if (!ex) ex = capture();
       if (ex) e = insert_graph(h, key, ex, tuned, stage == 0 ? h->fork_name : nullptr, false, st);

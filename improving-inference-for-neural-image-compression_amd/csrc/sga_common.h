@@ -104,8 +104,6 @@ struct ConvArgs {
   // fused IGDN post-phase (256-row unsplit C = 192 launches): out = u, post_s = sqrt(n), post_v = u * sqrt(n)
   int post; const float* post_w; const float* post_beta; float* post_s; float* post_v;
   const unsigned short* post_wx3;      // gamma pre-split into three bf16 planes (X3 instances), layout as `w3`
-  // ... and, with the IGDN, the products of the layer after it (C -> 3): post_p [pixel][80] = post_v . post_w3 (or null)
-  const float* post_w3; float* post_p;
   const float* zeros;      // >= 256 bytes of zeros: what taps outside the image load (LDS-DMA instance)
 #ifdef SGA_CLOCK_PROBE     // measurement build only (make PROBE=1): keeps the production kernels and their arguments unchanged
   unsigned long long* clk; // measurement only (SGA_CLOCK_PROBE=1, else null): per workgroup, shader-clock and 100 MHz
@@ -113,10 +111,7 @@ struct ConvArgs {
 #endif
   unsigned long long* stamp;   // measurement only (sga_profile_graph_begin), else null: [0] = min over workgroups of the 100 MHz
                            //   wall clock at entry, [1] = max at exit
-  int x3w4;                // bf16x3, 256-row tile without post-phase: the 4-wave instance (one wave per SIMD, 128 x 96 per wave)
   int reduce_batch;        // split-K reduce: issue the slab loads 8 at a time (main chain) or one by one
-  int deep;                // 64-row instance in its DEEP form (four LDS stages, counted waits; one workgroup per CU): laboratory, SGA_DEEP64
-  int lowfoot;             // 64-row instance in its low-footprint form (one LDS stage, 33 KB): hyper branch, SGA_SIDE_LOWFOOT=1
   int prio;                // wave priority (s_setprio) for the whole launch: experiment, SGA_MAIN_WAVE_PRIO / SGA_SIDE_WAVE_PRIO
   int side;                // the launch belongs to the hyper branch (its split-K reduce: SGA_SIDE_ELEM_PRIO)
   int xcd_remap;           // unsplit launch, tiles_per_phase % 8 == 0: XCD x (blocks b % 8 == x) walks a contiguous eighth of every
@@ -128,11 +123,6 @@ struct ConvArgs {
   int blk_begin[4];        //   gets splits in proportion and all workgroups walk ~equal K
   long long slab;
   float* part;
-  // split-K with the slab sum INSIDE the launch (round 5): every workgroup stores its slab write-through, takes a ticket of its
-  // output tile, and the LAST arriver sums the tile's slabs in the fixed order 0, 1, ... and applies the epilogue -- what
-  // splitk_reduce_kernel does, bit for bit, without a launch.  tickets: one zeroed counter per (phase, tile), reset by the
-  // last arriver; null: slabs only (a reduce launch or the consuming GDN kernel sums them)
-  unsigned* tickets;
   ConvPhase ph[4];
   ConvTap taps[28];
 };
@@ -187,11 +177,6 @@ struct GdnArgs {
   float* u_out;            // forward: T written back (needed when T was assembled here), or null
   double flops;            // algorithmic flops (profiling only)
   int prio;                // wave priority (experiment)
-  // persistent wave-specialised form of the backward pass with the gradient-convolution prologue (igdn_bwd_ws.hip):
-  const float* wf;         // gamma in MFMA fragment order [K/8][C/32][64 lanes][4] (pack_frag), or null
-  const float* wcf;        // the 3-channel kernel `wc` in the same order [12][C/32][64][4], or null
-  unsigned* sched;         // two zeroed counters (shared tile counter, exit counter), or null: tiles b, b + grid, ...
-  int ws;                  // 0: gdn_tile_kernel; 1: the persistent kernel when the launch has at least two tiles per CU; 2: whenever supported
 #ifdef SGA_CLOCK_PROBE
   unsigned long long* clk; // measurement build: per workgroup 8 x u64 = wall clock (100 MHz) at entry, after the prologue,
                            //   after the fill, after the contraction, at exit, hw_id | xcc_id << 32
@@ -200,9 +185,6 @@ struct GdnArgs {
 int launch_gdn_tile(const GdnArgs& a, hipStream_t stream);
 int gdn_tile_rows(int C, long long M, int pro);
 void gdn_kernel_name(const GdnArgs& a, char* out, int len);
-// igdn_bwd_ws.hip
-bool igdn_bwd_ws_supported(const GdnArgs& a);
-int launch_igdn_bwd_ws(const GdnArgs& a, hipStream_t stream);
 
 // C -> 3 transposed 5x5/2 conv, halo-tiled (deconv3.hip); w packed [C/32][9 taps][16][32]
 int launch_deconv3_halo(const float* in, const float* w, const float* bias, float* out, int B,

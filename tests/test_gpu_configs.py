@@ -469,6 +469,33 @@ def test_base_compress_inside_an_open_run():
     codec.close()
 
 
+def test_other_size_call_inside_an_open_run_keeps_the_zero_borders():
+    """the zero borders of the gradient image (`gpad`) are tracked per geometry.  A one-shot call at ANOTHER size
+    between two sga_run_steps calls re-zeroes them for its geometry; the run then wrote its own interior (another row pitch)
+    into what the handle still believed to be that geometry's borders, and a later gradient call at the one-shot size read stale
+    values at the image edges.  sga_run_steps re-checks the borders now: the one-shot evaluation gives the same bits before,
+    inside and after the run, and the interrupted run ends as the uninterrupted one."""
+    from sga_amd.codec import SGACodec
+    C, B = 64, 2
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    x = np.random.RandomState(4).rand(B, 64, 64, 3).astype(np.float32)          # the run's geometry
+    x2 = np.random.RandomState(5).rand(1, 96, 80, 3).astype(np.float32)         # the one-shot calls' geometry
+    codec = SGACodec(w, C, B, 96, 96)
+    ref = codec.run(x, 0.01, its=60, seed=5)
+    y2, z2 = codec.encode(x2)
+    idle = codec.step_grads(x2, y2, z2, 0.4, 0.01, seed=3, it=5)
+    codec.run_begin(x, 0.01, its=60, seed=5)
+    codec.run_steps(25)
+    mid = codec.step_grads(x2, y2, z2, 0.4, 0.01, seed=3, it=5)
+    codec.run_steps(35)
+    after = codec.step_grads(x2, y2, z2, 0.4, 0.01, seed=3, it=5)                 # the call that used to see stale borders
+    y, z = codec.run_latents()
+    assert torch.equal(torch.round(y), ref[0]) and torch.equal(torch.round(z), ref[1])
+    for r in (mid, after):
+        assert torch.equal(r["gy"], idle["gy"]) and torch.equal(r["gz"], idle["gz"]) and r["rd_loss"] == idle["rd_loss"]
+    codec.close()
+
+
 def test_bits_back_step_at_kodak_size_trained_like_weights(gpu_out_dir):
     """cfg 5 at Kodak size WITHOUT touching the posterior: the bits-back model fitted by
     tests/tools/fit_weights.py (C = 64; log-variances 0.5 .. 3.1) needs no clipping of (z_mean, z_logvar) and no scaled

@@ -6,7 +6,7 @@ same order, so the two paths must agree BIT FOR BIT -- in the encoder (GDN forwa
 nn_models.py:17-25), in one SGA step (IGDN forward / backward, nn_models.py:51-59) and over a short
 run.  Parity of either path with the oracle is covered by the other GPU test files.
 
-The ablation switches (SGA_FUSED_GDN, SGA_KEEP_U, SGA_POST_P, SGA_FUSED_POST64, SGA_GS3_GEMM, SGA_FUSED_MSE, SGA_FUSED_BOUNDARY,
+The ablation switches (SGA_FUSED_GDN, SGA_KEEP_U, SGA_FUSED_POST64, SGA_GS3_GEMM, SGA_FUSED_MSE, SGA_FUSED_BOUNDARY,
 SGA_FORK_AT, SGA_FORK2_NAME) exist only in the LABORATORY build of the library (`make EXPERIMENTS=1` -> libsga_hip_lab.so,
 `SGACodec(..., lab=True)`); the product library has none of them (tests/test_host.py).  With no switch set the two builds
 run the same launches: `test_lab_build_equals_the_product_build` checks that bit for bit."""
@@ -28,11 +28,9 @@ def _pair(C, B, H, W):
     the oracle everywhere else)."""
     from sga_amd.codec import SGACodec
     w = sga_amd.make_synthetic_weights(C, seed=0)
-    old = {k: os.environ.get(k) for k in ("SGA_FUSED_GDN", "SGA_KEEP_U", "SGA_POST_P")}
+    old = {k: os.environ.get(k) for k in ("SGA_FUSED_GDN", "SGA_KEEP_U")}
     try:
-        # (SGA_POST_P=0: the C -> 3 layer by the halo kernel on both sides; its products formed in the post-phase are
-        # compared with the stand-alone GEMM in test_post_phase_products_equal_the_standalone_gemm)
-        os.environ["SGA_FUSED_GDN"] = "1"; os.environ["SGA_KEEP_U"] = "1"; os.environ["SGA_POST_P"] = "0"
+        os.environ["SGA_FUSED_GDN"] = "1"; os.environ["SGA_KEEP_U"] = "1"
         fused = SGACodec(w, C, B, H, W, lab=True)
         os.environ["SGA_FUSED_GDN"] = "0"
         legacy = SGACodec(w, C, B, H, W, lab=True)
@@ -192,41 +190,6 @@ def test_gs3_as_gemm_plus_col2im_equals_the_halo_kernel(C, B, H, W):
     gemm.close(); halo.close()
 
 
-# (shapes whose gs2.fwd the planner runs as unsplit 256-row tiles with the post-phase; 512 x 490: ragged, cropped output)
-@pytest.mark.parametrize("C,B,H,W", [(192, 2, 512, 512), (192, 4, 512, 490), (192, 8, 256, 256)])
-def test_post_phase_products_equal_the_standalone_gemm(C, B, H, W):
-    """SGA_POST_P=1 (opt-in experiment, DESIGN_EXPERIMENTS.md A.6: no gain in the iteration): at C = 192, when gs2.fwd
-    fuses the IGDN, its post-phase also forms the C -> 3 layer's products P = v . W3 (nn_models.py:60-63) while v is on
-    chip, and the layer is only the col2im kernel.  Against the same layer with P from the stand-alone GEMM
-    (SGA_GS3_GEMM=1): the same MFMA sequence, so the step, a short run and the evaluation agree BIT FOR BIT."""
-    from sga_amd.codec import SGACodec
-    w = sga_amd.make_synthetic_weights(C, seed=0)
-    old = {k: os.environ.get(k) for k in ("SGA_POST_P", "SGA_GS3_GEMM")}
-    try:
-        os.environ["SGA_POST_P"] = "1"; os.environ.pop("SGA_GS3_GEMM", None)
-        ships = SGACodec(w, C, B, H, W, lab=True)
-        os.environ["SGA_POST_P"] = "0"; os.environ["SGA_GS3_GEMM"] = "1"
-        ref = SGACodec(w, C, B, H, W, lab=True)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    x = np.random.RandomState(C + H).rand(B, H, W, 3).astype(np.float32)
-    y, z = ships.encode(x)
-    ra = ships.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
-    rb = ref.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
-    assert torch.equal(ra["gy"], rb["gy"]) and torch.equal(ra["gz"], rb["gz"]) and float(ra["gy"].abs().max()) > 0
-    assert ra["train_mse"] == pytest.approx(rb["train_mse"], rel=1e-6)
-    a, b = ships.run(x, 0.01, its=10, seed=1), ref.run(x, 0.01, its=10, seed=1)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    assert torch.allclose(a[2][:, [0, 1, 4, 5, 6]], b[2][:, [0, 1, 4, 5, 6]], rtol=1e-6, atol=0)
-    (ma, xa), (mb, xb) = ships.evaluate(x, a[0], a[1], want_x_hat=True), ref.evaluate(x, a[0], a[1], want_x_hat=True)
-    assert torch.equal(xa, xb)
-    ships.close(); ref.close()
-
-
 def test_results_do_not_depend_on_the_schedule(monkeypatch):
     """where the hyper branch is forked (timed per geometry in runs of >= 100 iterations), whether it is forked
     at all, and whether the step graph is replayed or launched eagerly are schedule choices -- the same kernels with the same
@@ -279,65 +242,3 @@ def test_lab_build_equals_the_product_build():
     a, b = prod.run(x, 0.01, its=120, seed=1), lab.run(x, 0.01, its=120, seed=1)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     prod.close(); lab.close()
-
-
-# the last synthesis stage's IGDN data-gradient (with the C -> 3 layer's data-gradient in it) as the persistent,
-# wave-specialised kernel of round 5 (csrc/igdn_bwd_ws.hip) against the tile kernel it replaces (csrc/gdn_fused.hip):
-# same 32 x 96 blocks per wave, same K order, same elementwise expressions -> BIT-equal.  The persistent kernel is a
-# LABORATORY alternative (libsga_hip_lab.so; it is faster alone and slower inside the iteration, DESIGN_EXPERIMENTS.md A.10):
-# SGA_IGDN_WS=2 forces it at every supported shape, =1 from two tiles per CU, =0 (default) is the tile kernel.
-WS_SHAPES = [(192, 8, 256, 256),          # cfg 2: 2048 tiles, eight per CU
-             (192, 1, 256, 256),          # 256 tiles: one per workgroup (no steady state: prologue -> one phase -> drain)
-             (192, 1, 64, 48),            # 12 tiles: a grid smaller than the chip
-             (192, 2, 200, 264),          # ragged: latents 13 x 17, crops, a partial last tile
-             (64, 2, 64, 64), (64, 1, 50, 70), (128, 3, 37, 41), (128, 2, 512, 512),
-             (192, 3, 512, 768)]          # Kodak, three images: 9216 tiles, 36 per CU
-
-
-@pytest.mark.parametrize("C,B,H,W", WS_SHAPES)
-@pytest.mark.parametrize("sched", ["dynamic", "static"])
-def test_persistent_igdn_bwd_equals_the_tile_kernel(C, B, H, W, sched, monkeypatch):
-    """nn_models.py:59-63 backward (its part of sga.py:164)."""
-    from sga_amd.codec import SGACodec
-    w = sga_amd.make_synthetic_weights(C, seed=0)
-    monkeypatch.setenv("SGA_IGDN_WS_SCHED", sched)
-    monkeypatch.setenv("SGA_IGDN_WS", "2")
-    ws = SGACodec(w, C, B, H, W, lab=True)
-    monkeypatch.setenv("SGA_IGDN_WS", "0")
-    tile = SGACodec(w, C, B, H, W, lab=True)
-    x = np.random.RandomState(C + H).rand(B, H, W, 3).astype(np.float32)
-    y, z = tile.encode(x)
-    # (the profiled call only shows which kernel ran: profiling is single-stream, and at large shapes the hyper branch's split-K
-    #  slab count is capped by the buffer of the stream it runs on -- another summation order than the two-stream step)
-    ws.profile_begin(); ws.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5); names = [k["name"] for k in ws.profile_end()]
-    assert any(n.replace(" ", "").startswith("igdn_bwd_ws_kernel<%d>" % (C // 32)) for n in names), names
-    ra = ws.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
-    rb = tile.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
-    assert float(ra["gy"].abs().max()) > 0
-    assert torch.equal(ra["gy"], rb["gy"]) and torch.equal(ra["gz"], rb["gz"]) and ra["rd_loss"] == rb["rd_loss"]
-    # repeated launches (the shared tile counter must be back at zero) and the graph replay
-    for _ in range(3):
-        rc = ws.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
-        assert torch.equal(rc["gy"], rb["gy"])
-    its = 8 if H * W > 40000 else 20
-    a = ws.run(x, 0.01, its=its, seed=1); b = tile.run(x, 0.01, its=its, seed=1)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    ws.close(); tile.close()
-
-
-def test_persistent_igdn_bwd_with_stored_u_equals_the_tile_kernel(monkeypatch):
-    """SGA_KEEP_U=1 (laboratory): the IGDN stores its input and the data-gradient reads it instead of forming v / s."""
-    from sga_amd.codec import SGACodec
-    C, B, H, W = 192, 2, 256, 256
-    w = sga_amd.make_synthetic_weights(C, seed=0)
-    monkeypatch.setenv("SGA_KEEP_U", "1")
-    monkeypatch.setenv("SGA_IGDN_WS", "2")
-    ws = SGACodec(w, C, B, H, W, lab=True)
-    monkeypatch.setenv("SGA_IGDN_WS", "0")
-    tile = SGACodec(w, C, B, H, W, lab=True)
-    x = np.random.RandomState(5).rand(B, H, W, 3).astype(np.float32)
-    y, z = tile.encode(x)
-    ra = ws.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
-    rb = tile.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
-    assert torch.equal(ra["gy"], rb["gy"]) and torch.equal(ra["gz"], rb["gz"])
-    ws.close(); tile.close()

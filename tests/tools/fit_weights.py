@@ -11,6 +11,7 @@ fitted_weights_c64.json).  Deterministic inputs; the stored file, not a re-run o
 
     python tests/tools/fit_weights.py [steps=4000]        # ~10 min on 3 cores
     FIT_C=192 NTHREADS=4 python tests/tools/fit_weights.py 4000   # -> fitted_weights_c192.npz (round 5)
+    FIT_C=256 FIT_LMBDA=0.08 NTHREADS=4 python tests/tools/fit_weights.py 4000   # -> fitted_weights_c256.npz (round 6: cfg 4's width and rate point)
     python tests/tools/fit_weights.py 4000 bb             # the mbt2018_bb model (cfg 5: h_a emits mean | logvar, bb_sga.py:69)
                                                           # -> fitted_weights_c64bb.npz, objective = the bits-back ELBO
 """
@@ -29,7 +30,8 @@ import sga_amd
 from oracle.sga_oracle import SGAOracle, lower_bound, LIKELIHOOD_BOUND, SCALES_MIN
 
 C = int(os.environ.get("FIT_C", "64"))        # FIT_C=192: the north star's width (round 5; ~40 min on 4 cores)
-H, W, BATCH, LMBDA = 64, 64, 8, 0.01
+H, W, BATCH = 64, 64, 8
+LMBDA = float(os.environ.get("FIT_LMBDA", "0.01"))      # FIT_LMBDA=0.08: cfg 4's rate point (README.md:60,105), used for C = 256 (round 6)
 OUT = os.path.join(ROOT, "tests", "golden", "fitted_weights_c%d" % C)
 
 

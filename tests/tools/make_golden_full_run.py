@@ -81,6 +81,19 @@ CFGS = {
     # seed 0 of "cfg2_fitted" with its per-iteration trace kept: the production schedule step by step at a codec's operating point
     "cfg2_fitted_trace2000": dict(C=192, B=8, H=256, W=256, its=2000, lmbda=0.01, x_seed=27, weight_seed=0, scale_bound=0.0,
                                   weights="fitted_c192", inputs="lowpass", trace=True, seeds=[0]),
+    # ---- round 6: COMPLETE runs at the REAL sizes of BASELINE.json's configs 3, 4 and 5, one image, one seed, the
+    # per-iteration trace kept, on trained-like models (raw sigma: neither sga.py:130-133 nor bb_sga.py:121-124 builds the layer).
+    # NTHREADS=<n> gives the one run n oracle threads (a run is serial in its 2000 iterations).
+    # cfg 3: one Kodak-size image (512 x 768, landscape), C = 192, lambda = 0.01 (sga.py:201-247, configs.py:5-9)
+    "cfg3_kodak_trace2000": dict(C=192, B=1, H=512, W=768, its=2000, lmbda=0.01, x_seed=31, weight_seed=0, scale_bound=0.0,
+                                 weights="fitted_c192", inputs="lowpass", trace=True, seeds=[0]),
+    # cfg 5: the same image through bb_sga.py:199-276 (2000 SGA iterations + 2000 rate-only iterations), the fitted bits-back model
+    "cfg5_kodak_trace2000": dict(C=192, B=1, H=512, W=768, its=2000, r_its=2000, lmbda=0.01, x_seed=31, weight_seed=0, bb=True,
+                                 scale_bound=0.0, weights="fitted_c192bb", inputs="lowpass", trace=True, seeds=[0]),
+    # cfg 4: one Tecnick-size image (1200 x 1200: ragged 75 x 75 latents, 76 -> 75 crop live), C = 256 fitted at the config's rate
+    # point lambda = 0.08 (`FIT_C=256 FIT_LMBDA=0.08 tests/tools/fit_weights.py`); ~2 s per iteration on 8 cores
+    "cfg4_tecnick_trace2000": dict(C=256, B=1, H=1200, W=1200, its=2000, lmbda=0.08, x_seed=33, weight_seed=0, scale_bound=0.0,
+                                   weights="fitted_c256", inputs="lowpass", trace=True, seeds=[0]),
     # CONTROL for the statistical criterion: the small set's inputs and Philox seeds through the float64 oracle.  The
     # float32-vs-float64 ORACLE difference is what "a different rounding of the same arithmetic" does to a 2000-step run;
     # tests/test_oracle.py asserts it has the spread the GPU acceptance test tolerates
@@ -155,7 +168,7 @@ def run_resumable(orc, x, lmbda, its, seed, trace, t0, r, ckpt, progress=None, e
 def one_seed(seed):
     import numpy as np
     import torch
-    torch.set_num_threads(1)
+    torch.set_num_threads(int(os.environ.get("NTHREADS", "1")))
     import sga_amd
     from oracle.sga_oracle import SGAOracle
     w = make_weights(CFG)
@@ -163,11 +176,11 @@ def one_seed(seed):
     t = time.time()
     orc = SGAOracle(w, dtype=getattr(torch, CFG.get("dtype", "float32")), scale_bound=CFG["scale_bound"])
     if CFG.get("bb"):
-        y_hat, z_hat, m, _, _ = orc.bb_run(x, CFG["lmbda"], its=CFG["its"], r_its=CFG["r_its"], seed=seed)
+        y_hat, z_hat, m, tr, tr2 = orc.bb_run(x, CFG["lmbda"], its=CFG["its"], r_its=CFG["r_its"], seed=seed, trace=bool(CFG.get("trace")))
     else:
         prog = (lambda it, st: print("seed %d it %d rd_loss %.4f %.0f s" % (seed, it, st["rd_loss"], time.time() - t),
                                      flush=True)) if os.environ.get("PROGRESS") else None
-        if CFG["H"] * CFG["W"] * CFG["B"] >= 8 * 256 * 256 and CFG.get("dtype", "float32") == "float32":      # hours per seed: resumable
+        if CFG["H"] * CFG["W"] * CFG["B"] >= 512 * 768 and CFG.get("dtype", "float32") == "float32":      # hours per seed: resumable
             os.makedirs(CKPT_DIR, exist_ok=True)
             y_hat, z_hat, m, tr = run_resumable(orc, x, CFG["lmbda"], CFG["its"], seed, bool(CFG.get("trace")), CFG.get("t0", 700),
                                                 CFG.get("annealing_rate", 1e-3), os.path.join(CKPT_DIR, "%s_seed%d.npz" % (NAME, seed)), prog)
@@ -184,6 +197,8 @@ def one_seed(seed):
         out["est_bpp_back"] = m["est_bpp_back"].astype(np.float64).tolist()
     if CFG.get("trace"):
         out["trace"] = np.asarray(tr, np.float64).tolist()
+        if CFG.get("bb"):
+            out["trace2"] = np.asarray(tr2, np.float64).tolist()      # stage 2: the rate-only objective per iteration (bb_sga.py:249-261)
         out["frac_nonzero_y_hat"] = float((y_hat != 0).mean())
     return out
 
