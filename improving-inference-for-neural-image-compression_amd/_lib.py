@@ -155,12 +155,67 @@ def load_library(path: str | None = None):
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("SGA_CALL_LOG"):
+        lib = _CallLog(lib, os.environ["SGA_CALL_LOG"])
     ver = lib.sga_abi_version()
     if ver != SGA_ABI_VERSION:
         raise RuntimeError(f"libsga_hip ABI version {ver} != expected {SGA_ABI_VERSION}")
     if path is None:
         _lib = lib
     return lib
+
+
+class _CallLog:
+    """Debugging aid (SGA_CALL_LOG=<file>): every C-ABI call of this process as one text line -- the entry point, then its
+    arguments in order: integers and floats by value, a handle as `h<n>` (n-th handle created), any other pointer as `P` / `0`
+    (non-null / null), the members of sga_config for sga_create -- flushed BEFORE the call is made, so the last line of a
+    crashed process is the call it died in.  `tests/c_client/sga_replay.cpp` replays such a file against the library from
+    a process without Python or PyTorch (round 6: the hunt for the host SIGSEGV after mid-life hipGraphExecDestroy)."""
+
+    def __init__(self, lib, path):
+        self._lib, self._f, self._handles = lib, open(path, "a"), {}
+
+    def _fmt(self, v):
+        if isinstance(v, bool):
+            return str(int(v))
+        if isinstance(v, int):
+            return str(v)
+        if isinstance(v, float):
+            return repr(v)
+        if isinstance(v, bytes):
+            return "S:" + v.decode(errors="replace").replace(" ", "_")
+        if v is None:
+            return "0"
+        val = getattr(v, "value", None)
+        if isinstance(v, C.c_void_p):
+            if val in self._handles:
+                return "h%d" % self._handles[val]
+            return "P" if val else "0"
+        if isinstance(val, (int, float)) and not isinstance(v, (C.c_char_p,)):
+            return self._fmt(val)
+        return "P"
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("sga_"):
+            return fn
+
+        def call(*args):
+            if name == "sga_create":
+                cfg = args[1]._obj
+                line = "sga_create %d %d %d %d %d %d %r" % (cfg.num_filters, cfg.max_batch, cfg.max_height, cfg.max_width,
+                                                          cfg.bits_back, cfg.precision, cfg.scale_bound)
+            else:
+                line = name + " " + " ".join(self._fmt(a) for a in args)
+            self._f.write(line + "\n")
+            self._f.flush()
+            rc = fn(*args)
+            if name == "sga_create" and rc == 0:
+                self._handles[args[0]._obj.value] = len(self._handles)
+            if name == "sga_destroy":
+                self._handles = {k: v for k, v in self._handles.items() if "h%d" % v != line.split()[1]}
+            return rc
+        return call
 
 
 class SgaError(RuntimeError):

@@ -548,18 +548,33 @@ class SGACodec:
                                  "y_hat / z_hat must hold integers; centred latents need compress_latents(..., centred=True)")
             zb = self._ec_encode_device(coder, z_sym, z_tab)
             yb = self._ec_encode_device(coder, ys["y_sym"], ys["y_tab"])
-            return ec.pack(tuple(x_shape), tuple(y_hat.shape), tuple(z_hat.shape), zb, yb, coder.table_mode,
+            return ec.pack(tuple(x_shape), tuple(y_hat.shape), tuple(z_hat.shape), zb, yb, self._stream_mode(coder),
                            coder.table_crc())
         zb = coder.encode_z(z_hat.cpu().numpy())
         yb = coder.encode_y(y_hat.cpu().numpy(), mu.cpu().numpy(), sigma.cpu().numpy())
-        return ec.pack(tuple(x_shape), tuple(y_hat.shape), tuple(z_hat.shape), zb, yb, coder.table_mode,
+        return ec.pack(tuple(x_shape), tuple(y_hat.shape), tuple(z_hat.shape), zb, yb, self._stream_mode(coder),
                        coder.table_crc())
+
+    def effective_precision(self) -> str:
+        """The arithmetic this handle's convolutions run in ("default" resolves through SGA_PRECISION like the library does)."""
+        p = self.precision
+        if p == "default":
+            p = os.environ.get("SGA_PRECISION", "f32")
+        return p if p in ("bf16x3", "bf16x2") else "f32"
+
+    def _stream_mode(self, coder) -> int:
+        from . import entropy_coding as ec
+        return coder.table_mode | (ec.MODE_PRECISIONS.index(self.effective_precision()) << ec.MODE_PRECISION_SHIFT)
 
     def decompress_latents(self, blob: bytes, on_device=True, medians=None):
         """-> (x_shape, y_hat, z_hat): z first, then (mu, sigma) = h_s(z_hat), then y.  The stream's mode byte says how its
         tables were built and whether it holds centred latents (then `medians` as at the encoder)."""
         from . import entropy_coding as ec
         x_shape, y_shape, z_shape, zb, yb, mode, crc = ec.unpack(blob, with_tables=True)
+        if ec.mode_precision(mode) != self.effective_precision():
+            raise ValueError("SGAC stream was coded by a handle in precision mode %r, this one runs in %r: its h_s would predict other "
+                             "(mu, sigma) and the range decoder would return garbage -- create the SGACodec with precision=%r"
+                             % (ec.mode_precision(mode), self.effective_precision(), ec.mode_precision(mode)))
         coder = self._entropy_coder(device_tables=bool(mode & 1), centred=bool(mode & 2), medians=medians)
         if coder.table_crc() != crc:
             raise ValueError("SGAC stream was coded with different CDF tables (mode %d, crc %08x; this decoder builds "

@@ -210,15 +210,43 @@ extern int g_deconv3_prio;
 #ifdef SGA_EXPERIMENTS
 #include <execinfo.h>
 #include <signal.h>
+#include <ucontext.h>
 #include <unistd.h>
-static void sga_segv_handler(int sig) {      // debugging aid (SGA_DEBUG_SEGV=1): native frames of a crash inside the library
-  void* frames[64];
-  const int n = backtrace(frames, 64);
-  const char msg[] = "sga: fatal signal, native backtrace:\n";
-  (void)!write(2, msg, sizeof(msg) - 1);
-  backtrace_symbols_fd(frames, n, 2);
+// debugging aid (SGA_DEBUG_SEGV=1): native frames of a crash inside the process.  Runs on its OWN stack (sigaltstack): a
+// handler on the faulting stack cannot run when the fault IS the stack (round 6: the handler of rounds 4-5 printed nothing and
+// the process died with rc 139 -- which is what a stack overflow looks like).  Prints the faulting address, the stack pointer,
+// the depth of the call stack, its innermost and its outermost frames.
+static void* g_segv_frames[1 << 20];
+static void sga_segv_handler(int sig, siginfo_t* si, void* uc_) {
+  const ucontext_t* uc = (const ucontext_t*)uc_;
+  char buf[256];
+  const int n = backtrace(g_segv_frames, 1 << 20);
+  int len = snprintf(buf, sizeof(buf), "sga: fatal signal %d, fault address %p, rsp %p, %d frames; innermost:\n", sig, si->si_addr,
+                     (void*)uc->uc_mcontext.gregs[REG_RSP], n);
+  (void)!write(2, buf, (size_t)len);
+  backtrace_symbols_fd(g_segv_frames, n < 48 ? n : 48, 2);
+  if (n > 96) {
+    const char msg[] = "sga: ... outermost:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(g_segv_frames + n - 48, 48, 2);
+  } else if (n > 48) {
+    backtrace_symbols_fd(g_segv_frames + 48, n - 48, 2);
+  }
   signal(sig, SIG_DFL);
   raise(sig);
+}
+static void sga_install_segv_handler() {
+  static char alt[1 << 18];
+  stack_t ss;
+  ss.ss_sp = alt; ss.ss_size = sizeof(alt); ss.ss_flags = 0;
+  (void)sigaltstack(&ss, nullptr);
+  struct sigaction sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_sigaction = sga_segv_handler;
+  sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+  sigemptyset(&sa.sa_mask);
+  (void)sigaction(SIGSEGV, &sa, nullptr);
+  (void)sigaction(SIGBUS, &sa, nullptr);
 }
 #endif
 
@@ -1462,7 +1490,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return SGA_ERR_NO_DEVICE;
 #ifdef SGA_EXPERIMENTS
-  if (LAB_ENV("SGA_DEBUG_SEGV")) { signal(SIGSEGV, sga_segv_handler); signal(SIGBUS, sga_segv_handler); }
+  if (LAB_ENV("SGA_DEBUG_SEGV")) sga_install_segv_handler();
 #endif
   sga_handle* h = new (std::nothrow) sga_handle();
   if (!h) return SGA_ERR_NOMEM;

@@ -485,14 +485,16 @@ def decompress(args, weights=None):
     from . import entropy_coding as ec
     with open(args.input_file, "rb") as f:
         blob = f.read()
-    (B, H, W) = ec.unpack(blob)[0]
+    (B, H, W), mode = ec.unpack(blob)[0], ec.unpack(blob, with_tables=True)[5]
     if weights is None:
         if args.synthetic_weights:
             weights = make_synthetic_weights(args.num_filters, seed=0)
         else:
             from .tf_checkpoint import load_effective_weights
             weights = load_effective_weights(os.path.join(args.checkpoint_dir, args.runname), args.num_filters)
-    codec = SGACodec(weights, args.num_filters, B, H, W, device="cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
+    # the decoder's h_s must run in the arithmetic the encoder's ran in: the stream says which (entropy_coding.MODE_PRECISIONS)
+    codec = SGACodec(weights, args.num_filters, B, H, W, device="cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")),
+                     precision=ec.mode_precision(mode))
     try:
         _, y_hat, _ = codec.decompress_latents(blob)
         x_hat = codec.reconstruct(y_hat, H, W).cpu().numpy()

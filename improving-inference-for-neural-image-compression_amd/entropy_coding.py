@@ -36,7 +36,10 @@ SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64          # sga.py:24-26
 MEAN_BINS = 8
 MAGIC = b"SGAC"
 BLOCK = 1024            # symbols per independent rANS stream (one device lane each; 8 bytes of overhead per block): the FIRST pass
-BLOCK_MAX = 1 << 16     # ... and the largest block the second pass may choose
+BLOCK_MAX = 1 << 13     # ... and the largest block the second pass may choose.  A block is ONE device lane (csrc/rans.hip): at the
+                        # trained-like operating point 65536-symbol blocks left ~5 lanes and saved 2.4 % of the bytes of 4096-symbol
+                        # blocks for 3-4 x the device time (profiles/r05_coder_timing.txt: encode 5.1 -> 16.7 ms, decode 6.9 -> 27.7 ms;
+                        # 16384 -> 65536 saves 0.03 %).  8192 keeps the framing under ~1 % there
 BLOCK_TARGET_BYTES = 512
 
 
@@ -355,13 +358,22 @@ class EntropyCoder:
         return float(-np.log2(f / TOTAL).sum() + 32.0 * esc.sum())
 
 
-FORMAT_VERSION = 2      # 1 (round 2, magic only) had no table fingerprint
+FORMAT_VERSION = 3      # 1 (round 2, magic only) had no table fingerprint; 2 (rounds 3-5) did not say in which arithmetic (mu, sigma) were
+                        # computed, and its second pass chose blocks of up to 65536 symbols (same framing: format 3 reads format-2 bodies)
+# the container's mode byte: bit 0 tables built on the device, bit 1 centred latents, bits 2-3 the precision mode of the handle whose
+# h_s produced (mu, sigma) -- a decoder in another mode computes other sigma levels and decodes garbage --, bits 4-7 zero
+MODE_PRECISION_SHIFT, MODE_PRECISION_MASK, MODE_KNOWN_BITS = 2, 3, 0x0F
+MODE_PRECISIONS = ("f32", "bf16x3", "bf16x2")
+
+
+def mode_precision(table_mode: int) -> str:
+    return MODE_PRECISIONS[(table_mode >> MODE_PRECISION_SHIFT) & MODE_PRECISION_MASK]
 
 
 def pack(x_shape, y_shape, z_shape, z_bytes: bytes, y_bytes: bytes, table_mode: int = 0, table_crc: int = 0) -> bytes:
     """Container (cf. tfc.PackedTensors, mbt2018.py:211-214): magic, format version, how the coder's CDF tables were
-    built (bit 0: 0 = host float64 numpy, 1 = device float32 kernels; bit 1: centred latents, mbt2018.py compress) and their
-    CRC32, shapes, two length-prefixed streams.
+    built (bit 0: 0 = host float64 numpy, 1 = device float32 kernels; bit 1: centred latents, mbt2018.py compress; bits 2-3: the
+    arithmetic of the h_s that gave (mu, sigma): 0 f32, 1 bf16x3, 2 bf16x2) and their CRC32, shapes, two length-prefixed streams.
     A range coder needs bit-identical tables on both sides: the decoder refuses a stream whose fingerprint is not its own."""
     head = MAGIC + struct.pack("<BBHI", FORMAT_VERSION, table_mode, 0, table_crc & 0xFFFFFFFF)
     head += struct.pack("<3I4I4I", *x_shape, *y_shape, *z_shape)
@@ -378,7 +390,10 @@ def unpack(blob: bytes, with_tables: bool = False):
     version, table_mode, _, table_crc = struct.unpack("<BBHI", blob[4:12])
     if version != FORMAT_VERSION:
         raise ValueError(f"SGAC stream format {version}, this build reads format {FORMAT_VERSION} "
-                         + ("(format 1, round 2, carried no table fingerprint: re-encode the latents)" if version == 1 else ""))
+                         + ("(format 1, round 2, carried no table fingerprint: re-encode the latents)" if version == 1 else
+                            "(format 2 did not record the precision mode of its encoder: re-encode the latents)" if version == 2 else ""))
+    if (table_mode & ~MODE_KNOWN_BITS) or ((table_mode >> MODE_PRECISION_SHIFT) & MODE_PRECISION_MASK) >= len(MODE_PRECISIONS):
+        raise ValueError(f"SGAC stream: unknown bits in the mode byte ({table_mode:#04x}); written by a newer build?")
     if len(blob) < 56 + 8:
         raise ValueError("corrupt stream: truncated SGAC header")
     v = struct.unpack("<3I4I4I", blob[12:56])

@@ -181,6 +181,16 @@ def test_unpack_refuses_malformed_blobs(coder):
             ec.unpack(bad)
     with pytest.raises(ValueError, match="format 1"):
         ec.unpack(blob[:4] + b"\x01" + blob[5:])
+    with pytest.raises(ValueError, match="format 2"):              # rounds 3-5: no precision mode in the mode byte
+        ec.unpack(blob[:4] + b"\x02" + blob[5:])
+    # the mode byte: bits 2-3 name the arithmetic of the encoder's h_s, the other bits must be zero
+    for prec, name in enumerate(ec.MODE_PRECISIONS):
+        b2 = ec.pack((1, 64, 64), (1, 4, 4, 64), (1, 1, 1, 64), b"zz", b"yyyy", 1 | (prec << ec.MODE_PRECISION_SHIFT), 0x1234)
+        assert ec.mode_precision(ec.unpack(b2, with_tables=True)[5]) == name
+    for bad_mode in (0x10, 0x80, 0x0C | 1):                        # unknown bits; precision code 3
+        with pytest.raises(ValueError, match="mode byte"):
+            ec.unpack(blob[:5] + bytes([bad_mode]) + blob[6:])
+    assert ec.adapted_block(np.array([3, 4, 5])) <= 8192           # a block is one device lane: never fewer, bigger lanes than this
 
 
 def test_host_coder_equals_the_rans_oracle_byte_for_byte(coder):

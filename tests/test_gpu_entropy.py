@@ -72,6 +72,30 @@ def test_device_rans_bytes_equal_the_host_coder(C, B, H, W, its, gpu_out_dir):
     codec.close()
 
 
+def test_stream_names_the_precision_mode_of_its_encoder():
+    """(mu, sigma) = h_s(z_hat) follow the handle's precision mode, and a range decoder needs the encoder's sigma levels
+    bit for bit.  The container's mode byte records the mode (format 3): a handle in another mode REFUSES the stream with a message
+    that says which mode to create instead of decoding garbage; a handle in the same mode decodes it exactly."""
+    from sga_amd import entropy_coding as ec
+    from sga_amd.codec import SGACodec
+    C, B, H, W = 64, 1, 64, 80
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    x = np.random.RandomState(3).rand(B, H, W, 3).astype(np.float32)
+    fast, f32 = SGACodec(w, C, B, H, W, precision="bf16x2"), SGACodec(w, C, B, H, W)
+    y_hat, z_hat, _, _ = fast.run(x, 0.01, its=20, seed=2)
+    blob = fast.compress_latents((B, H, W), y_hat, z_hat)
+    assert ec.mode_precision(ec.unpack(blob, with_tables=True)[5]) == "bf16x2"
+    _, y2, z2 = fast.decompress_latents(blob)
+    assert torch.equal(y2, y_hat) and torch.equal(z2, z_hat)
+    with pytest.raises(ValueError, match="precision='bf16x2'"):
+        f32.decompress_latents(blob)
+    blob32 = f32.compress_latents((B, H, W), y_hat, z_hat)
+    assert ec.mode_precision(ec.unpack(blob32, with_tables=True)[5]) == "f32"
+    with pytest.raises(ValueError, match="precision='f32'"):
+        fast.decompress_latents(blob32)
+    fast.close(); f32.close()
+
+
 def test_bits_back_coding_of_z_for_cfg5(gpu_out_dir):
     """cfg 5 (bb_sga.py): `est_bpp_back` (bb_sga.py:133-139) is an ESTIMATE in the reference.  bits_back.BitsBackCoder
     codes it for real on one ANS stack -- pop z_bar ~ Q(z | y), push y_hat | z_bar, push z_bar under the prior -- and the
