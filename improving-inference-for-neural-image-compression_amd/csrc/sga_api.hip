@@ -108,6 +108,15 @@ struct sga_handle {
   Buf* cur_part = nullptr;
   // hyper-prior branch runs on its own stream, forked/joined with events (also inside the graph)
   hipStream_t sB = nullptr;
+  // The stream every step GRAPH is captured and launched on: the library's own, HIGH priority (round 6).  Not for speed -- for the
+  // HIP runtime's Graph::UpdateStreams, which reads past the end of a graph's internal stream list when ALL of them share the
+  // LAUNCH stream's hardware queue (host SIGSEGV inside hipGraphLaunch: "defect (a)" of rounds 3-5, root cause and stand-alone
+  // reproducer in DESIGN_EXPERIMENTS.md A.13 / scripts/r06/graph_stream_collision_repro.hip).  The internal streams are created with
+  // NORMAL priority, and hardware queues are pooled per priority class: a launch stream of another class can never share one
+  // with them, whatever streams the process has created and destroyed before.  The caller's stream is bridged in and out
+  // with one event pair per call (LaunchStream below); null: graphs run on the caller's stream (laboratory: SGA_LAUNCH_STREAM=caller)
+  hipStream_t sG = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;           // eager launches
   const char* dump_path = nullptr; unsigned long long* dump = nullptr; int dump_run = 0;   // SGA_DEBUG_DUMP
   bool dump_probe = false;         // SGA_DEBUG_PROBE=1: ordering probe kernels (k_mark / k_probe) with the dump
@@ -209,6 +218,7 @@ extern int g_deconv3_prio;
 
 #ifdef SGA_EXPERIMENTS
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
 #include <ucontext.h>
 #include <unistd.h>
@@ -217,26 +227,59 @@ extern int g_deconv3_prio;
 // the process died with rc 139 -- which is what a stack overflow looks like).  Prints the faulting address, the stack pointer,
 // the depth of the call stack, its innermost and its outermost frames.
 static void* g_segv_frames[1 << 20];
+static int g_segv_fd = 2;      // SGA_DEBUG_SEGV=<path>: the report goes to that file (pytest captures fd 2: a report written there is lost with the process)
 static void sga_segv_handler(int sig, siginfo_t* si, void* uc_) {
   const ucontext_t* uc = (const ucontext_t*)uc_;
-  char buf[256];
+  const greg_t* r = uc->uc_mcontext.gregs;
+  char buf[1024];
+  const int fd = g_segv_fd;
   const int n = backtrace(g_segv_frames, 1 << 20);
-  int len = snprintf(buf, sizeof(buf), "sga: fatal signal %d, fault address %p, rsp %p, %d frames; innermost:\n", sig, si->si_addr,
-                     (void*)uc->uc_mcontext.gregs[REG_RSP], n);
-  (void)!write(2, buf, (size_t)len);
-  backtrace_symbols_fd(g_segv_frames, n < 48 ? n : 48, 2);
-  if (n > 96) {
-    const char msg[] = "sga: ... outermost:\n";
-    (void)!write(2, msg, sizeof(msg) - 1);
-    backtrace_symbols_fd(g_segv_frames + n - 48, 48, 2);
-  } else if (n > 48) {
-    backtrace_symbols_fd(g_segv_frames + 48, n - 48, 2);
+  int len = snprintf(buf, sizeof(buf),
+                     "sga: fatal signal %d code %d, fault address %p, rip %p rsp %p rbp %p, %d frames\n"
+                     " rax %llx rbx %llx rcx %llx rdx %llx rsi %llx rdi %llx\n r8 %llx r9 %llx r10 %llx r11 %llx r12 %llx r13 %llx r14 %llx r15 %llx\n",
+                     sig, si->si_code, si->si_addr, (void*)r[REG_RIP], (void*)r[REG_RSP], (void*)r[REG_RBP], n,
+                     (unsigned long long)r[REG_RAX], (unsigned long long)r[REG_RBX], (unsigned long long)r[REG_RCX], (unsigned long long)r[REG_RDX],
+                     (unsigned long long)r[REG_RSI], (unsigned long long)r[REG_RDI], (unsigned long long)r[REG_R8], (unsigned long long)r[REG_R9],
+                     (unsigned long long)r[REG_R10], (unsigned long long)r[REG_R11], (unsigned long long)r[REG_R12], (unsigned long long)r[REG_R13],
+                     (unsigned long long)r[REG_R14], (unsigned long long)r[REG_R15]);
+  (void)!write(fd, buf, (size_t)len);
+  if ((void*)r[REG_RIP] != si->si_addr && r[REG_RIP] > 4096) {      // the faulting instruction's bytes (not when the fault IS the jump target)
+    const unsigned char* ip = (const unsigned char*)r[REG_RIP];
+    len = snprintf(buf, sizeof(buf), " code at rip:");
+    for (int i = 0; i < 24; ++i) len += snprintf(buf + len, sizeof(buf) - (size_t)len, " %02x", ip[i]);
+    len += snprintf(buf + len, sizeof(buf) - (size_t)len, "\n");
+    (void)!write(fd, buf, (size_t)len);
+  }
+  const char m1[] = "sga: innermost frames:\n";
+  (void)!write(fd, m1, sizeof(m1) - 1);
+  backtrace_symbols_fd(g_segv_frames, n < 64 ? n : 64, fd);
+  if (n > 128) {
+    const char msg[] = "sga: ... outermost frames:\n";
+    (void)!write(fd, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(g_segv_frames + n - 48, 48, fd);
+  } else if (n > 64) {
+    backtrace_symbols_fd(g_segv_frames + 64, n - 64, fd);
+  }
+  const char m2[] = "sga: /proc/self/maps:\n";
+  (void)!write(fd, m2, sizeof(m2) - 1);
+  const int mf = open("/proc/self/maps", O_RDONLY);
+  if (mf >= 0) {
+    for (;;) {
+      const ssize_t k = read(mf, buf, sizeof(buf));
+      if (k <= 0) break;
+      (void)!write(fd, buf, (size_t)k);
+    }
+    close(mf);
   }
   signal(sig, SIG_DFL);
   raise(sig);
 }
-static void sga_install_segv_handler() {
+static void sga_install_segv_handler(const char* where) {
   static char alt[1 << 18];
+  if (where && where[0] == '/' && g_segv_fd == 2) {
+    const int f = open(where, O_WRONLY | O_CREAT | O_APPEND, 0644);
+    if (f >= 0) g_segv_fd = f;
+  }
   stack_t ss;
   ss.ss_sp = alt; ss.ss_size = sizeof(alt); ss.ss_flags = 0;
   (void)sigaltstack(&ss, nullptr);
@@ -1341,10 +1384,26 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
 // the retire policy it has never crashed (9 full runs over two rounds).
 constexpr size_t kMaxRetired = 256;
 
+// The calls that replay step graphs run on the handle's own launch stream (sga_handle::sG): ordered after everything the caller
+// has enqueued on ITS stream so far, and the caller's stream ordered after them on the way out -- also on an error return.
+struct LaunchStream {
+  sga_handle* h;
+  hipStream_t user, run;
+  LaunchStream(sga_handle* h_, void* stream) : h(h_), user((hipStream_t)stream), run((hipStream_t)stream) {
+    if (h->sG && h->use_graph && hipEventRecord(h->ev_in, user) == hipSuccess && hipStreamWaitEvent(h->sG, h->ev_in, 0) == hipSuccess)
+      run = h->sG;
+  }
+  ~LaunchStream() {
+    if (run != user && (hipEventRecord(h->ev_out, run) != hipSuccess || hipStreamWaitEvent(user, h->ev_out, 0) != hipSuccess))
+      (void)hipStreamSynchronize(run);      // the ordering must hold even if the event pair failed
+  }
+};
+
 void drop_graph(sga_handle* h, hipGraphExec_t& ex, hipStream_t st = nullptr) {
   if (!ex) return;
   if (h->drop_destroy) {
     if (st) (void)hipStreamSynchronize(st);
+    if (h->sG) (void)hipStreamSynchronize(h->sG);      // (callers without a stream: sga_profile_graph_begin / _end)
     if (h->sB) (void)hipStreamSynchronize(h->sB);
     (void)hipGraphExecDestroy(ex);
   } else {
@@ -1356,6 +1415,7 @@ void drop_graph(sga_handle* h, hipGraphExec_t& ex, hipStream_t st = nullptr) {
     // same soak under SGA_GRAPH_DROP=destroy did not crash either: profiles/r05_soak_evictions.txt).
     if (h->retired_graphs.size() > kMaxRetired) {
       if (st) (void)hipStreamSynchronize(st);
+      if (h->sG) (void)hipStreamSynchronize(h->sG);
       if (h->sB) (void)hipStreamSynchronize(h->sB);
       const size_t n = h->retired_graphs.size() / 2;
       for (size_t i = 0; i < n; ++i) (void)hipGraphExecDestroy(h->retired_graphs[i]);
@@ -1470,6 +1530,9 @@ void free_all(sga_handle* h) {
   if (h->ev_fork_cap) (void)hipEventDestroy(h->ev_fork_cap);
   if (h->ev_join_cap) (void)hipEventDestroy(h->ev_join_cap);
   if (h->sB) (void)hipStreamDestroy(h->sB);
+  if (h->sG) (void)hipStreamDestroy(h->sG);
+  if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+  if (h->ev_out) (void)hipEventDestroy(h->ev_out);
   for (void* p : h->owned) (void)hipFree(p);
   h->owned.clear();
 }
@@ -1490,7 +1553,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return SGA_ERR_NO_DEVICE;
 #ifdef SGA_EXPERIMENTS
-  if (LAB_ENV("SGA_DEBUG_SEGV")) sga_install_segv_handler();
+  if (LAB_ENV("SGA_DEBUG_SEGV")) sga_install_segv_handler(LAB_ENV("SGA_DEBUG_SEGV"));
 #endif
   sga_handle* h = new (std::nothrow) sga_handle();
   if (!h) return SGA_ERR_NOMEM;
@@ -1709,7 +1772,6 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     // The side stream has normal priority (a high-priority one measured the same throughput).
     int prio = 0;
-    (void)lo; (void)hi;
     if (const char* pr = LAB_ENV("SGA_SIDE_PRIORITY")) prio = atoi(pr);   // experiments only
     const unsigned evflags = hipEventDisableTiming;
     // Experiment: SGA_SIDE_CU_MASK=<hex words, lowest first, comma separated> confines the hyper branch's
@@ -1731,6 +1793,13 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     // Experiment: SGA_HYBRID=1 runs the same hybrid replay with an unmasked side stream of priority SGA_SIDE_PRIORITY
     // (hardware-queue priorities act on eager streams; graph nodes ignore them)
     if (const char* hy = LAB_ENV("SGA_HYBRID")) h->side_hybrid = hy[0] == '1';
+    {
+      const char* ls = LAB_ENV("SGA_LAUNCH_STREAM");      // laboratory: "caller" = rounds 1-5 (graphs on the caller's stream), "low" = the other class
+      const bool own = !(ls && strcmp(ls, "caller") == 0);
+      if (own && (hipStreamCreateWithPriority(&h->sG, hipStreamNonBlocking, (ls && strcmp(ls, "low") == 0) ? lo : hi) != hipSuccess ||
+                  hipEventCreateWithFlags(&h->ev_in, evflags) != hipSuccess || hipEventCreateWithFlags(&h->ev_out, evflags) != hipSuccess))
+        return fail(SGA_ERR_HIP);
+    }
     if ((!masked && hipStreamCreateWithPriority(&h->sB, hipStreamNonBlocking, prio) != hipSuccess) ||
         hipEventCreateWithFlags(&h->ev_fork, evflags) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, evflags) != hipSuccess ||
@@ -1982,7 +2051,8 @@ int sga_run_begin(sga_handle* h, const float* x, int B, int H, int W, float lamb
 
 int sga_run_steps(sga_handle* h, int n, void* stream) {
   if (!h || n < 0 || h->run_its < 0) return SGA_ERR_BAD_ARG;
-  hipStream_t st = (hipStream_t)stream;
+  LaunchStream ls(h, stream);
+  hipStream_t st = ls.run;
   const int B = h->run_B, H = h->run_H, W = h->run_W, its = h->run_its;
   if (n > its - h->run_it) n = its - h->run_it;
   if (n == 0) return SGA_OK;
@@ -2703,7 +2773,8 @@ int sga_bb_run(sga_handle* h, const float* x, int B, int H, int W, float lambda,
   if (!h || !x || its < 0 || r_its < 0 || its > kMaxIts || r_its > kMaxIts) return SGA_ERR_BAD_ARG;
   if (!h->cfg.bits_back) return SGA_ERR_UNSUPPORTED;
   SGACHK(check_shape(h, B, H, W));
-  hipStream_t st = (hipStream_t)stream;
+  LaunchStream ls(h, stream);
+  hipStream_t st = ls.run;
   const Geom g = make_geom(B, H, W);
   const int C = h->C;
   const int64_t ny = (int64_t)B * g.yh * g.yw * C, nz2 = (int64_t)B * g.zh * g.zw * C * 2;
@@ -2764,7 +2835,8 @@ int sga_bb_refine(sga_handle* h, const float* y_hat, int B, int H, int W, float 
   if (!h || !y_hat || !zml_out || r_its < 0 || r_its > kMaxIts) return SGA_ERR_BAD_ARG;
   if (!h->cfg.bits_back) return SGA_ERR_UNSUPPORTED;
   SGACHK(check_shape(h, B, H, W));
-  hipStream_t st = (hipStream_t)stream;
+  LaunchStream ls(h, stream);
+  hipStream_t st = ls.run;
   const Geom g = make_geom(B, H, W);
   const int64_t ny = (int64_t)B * g.yh * g.yw * h->C, nz2 = (int64_t)B * g.zh * g.zw * h->C * 2;
   h->hT.assign(r_its > 0 ? r_its : 1, 1.f);

@@ -5,6 +5,8 @@ evaluation takes the CPU oracle a few seconds."""
 import json
 import os
 
+_TESTS = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))), "tests")      # frozen copy: fixtures live under tests/
+
 import numpy as np
 import pytest
 import torch
@@ -34,19 +36,13 @@ def test_step_at_config_shape(C, H, W, f64, sb, precision, gpu_out_dir):
     """encode + one SGA evaluation with Philox noise vs the oracle (float64 where it fits in a few
     seconds; the float32 oracle's own gz is only good to ~1e-2 at Kodak size, the HIP path agrees
     with float64 to 3e-6 there).  sb = sga_config.scale_bound.  At Tecnick size only the float32 oracle is
-    affordable.  There the RAW-sigma case (sb = 0: sga.py:130-133) runs on the C = 256 model FITTED at cfg 4's rate point
-    (round 6: tests/golden/fitted_weights_c256.npz, `FIT_C=256 FIT_LMBDA=0.08 tests/tools/fit_weights.py`) and a low-pass
-    image: rounds 2-5 ran it on the untrained weights, whose predicted scales go down to 7e-4 -- an element at
-    |y - mu| ~ 0.5 then has d(-log p)/dy ~ 1/sigma, the float32 rounding of mu moves its gradient by 1e-3 in either
-    float32 implementation, and the test carried a 10 x looser tolerance for it.  A trained-like model needs none
-    (shown at C = 192 in round 5): one set of bounds for every case now."""
+    affordable, and there the two modes need different tolerances: the untrained C = 256 weights predict scales
+    down to 7e-4, and with the raw sigma of sga.py:130-133 (sb = 0) an element at |y - mu| ~ 0.5 has
+    d(-log p)/dy ~ 1/sigma -- the float32 rounding of mu (1e-6) moves its gradient by 1e-6 / sigma ~ 1e-3 in either
+    float32 implementation; bounded at 0.11 the same step agrees to 2e-5."""
     from sga_amd.codec import SGACodec, metrics_to_dict
-    if C == 256 and H == 1200 and sb == 0.0:
-        w = sga_amd.load_weights_npz(os.path.join(os.path.dirname(__file__), "golden", "fitted_weights_c256.npz"))
-        x = sga_amd.make_lowpass_images(1, H, W, seed=43)
-    else:
-        w = sga_amd.make_synthetic_weights(C, seed=0)
-        x = np.random.RandomState(1).rand(1, H, W, 3).astype(np.float32)
+    w = sga_amd.make_synthetic_weights(C, seed=0)
+    x = np.random.RandomState(1).rand(1, H, W, 3).astype(np.float32)
     orc = SGAOracle(w, dtype=torch.float64 if f64 else torch.float32, scale_bound=sb)
     codec = SGACodec(w, C, 1, H, W, precision=precision, scale_bound=sb)
     yo, zo = SGAOracle(w).encode(x)
@@ -63,7 +59,8 @@ def test_step_at_config_shape(C, H, W, f64, sb, precision, gpu_out_dir):
                 rd_loss=abs(float(got["rd_loss"]) / float(want["rd_loss"]) - 1))
     report(gpu_out_dir, test="config_step", C=C, H=H, W=W, precision=precision, scale_bound=sb, **errs)
     assert errs["enc_y"] < 2e-5 and errs["enc_z"] < 2e-5, errs
-    assert errs["gy"] < 1e-4 and errs["gz"] < (1e-4 if f64 else 5e-4), errs
+    ill = (not f64) and sb == 0.0          # float32 oracle + raw sigma down to 7e-4: see the docstring
+    assert errs["gy"] < (1e-3 if ill else 1e-4) and errs["gz"] < (1e-4 if f64 else (5e-3 if ill else 5e-4)), errs
     assert errs["rd_loss"] < 1e-5, errs
     # a short complete run at this shape: finite metrics, objective improves, reproducible
     a = codec.run(x, lmbda, its=40, t0=10, annealing_rate=0.02, seed=2)
@@ -72,6 +69,33 @@ def test_step_at_config_shape(C, H, W, f64, sb, precision, gpu_out_dir):
     m, m0 = metrics_to_dict(a[2]), metrics_to_dict(codec.run(x, lmbda, its=0)[2])
     assert np.isfinite(m["est_bpp"]).all() and np.isfinite(m["psnr"]).all()
     assert (lmbda * m["mse"] + m["est_bpp"] < lmbda * m0["mse"] + m0["est_bpp"]).all()
+    codec.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_step_at_tecnick_size_trained_like_weights(precision, gpu_out_dir):
+    """The conditioning note of the test above, checked from the other side: with a TRAINED-LIKE model -- the
+    C = 192 weights fitted by tests/tools/fit_weights.py: predicted scales 0.087 (1 %) .. 0.098 (median) .. 6, never 7e-4 -- the
+    raw-sigma step (sga.py:130-133) at Tecnick size (1200 x 1200: ragged 75 x 75 latents, crops live) needs NO looser tolerance
+    against the float32 oracle: 1 / sigma <= 12, so the float32 rounding of mu moves a gradient by 1e-5, not 1e-3."""
+    from sga_amd.codec import SGACodec
+    C, H, W = 192, 1200, 1200
+    w = sga_amd.load_weights_npz(os.path.join(_TESTS, "golden", "fitted_weights_c192.npz"))
+    x = sga_amd.make_lowpass_images(1, H, W, seed=41)
+    orc = SGAOracle(w, dtype=torch.float32, scale_bound=0.0)
+    codec = SGACodec(w, C, 1, H, W, precision=precision, scale_bound=0.0)
+    yo, zo = orc.encode(x)
+    y, z = codec.encode(x)
+    assert rel_err(y.cpu().numpy(), yo.numpy()) < 2e-5 and rel_err(z.cpu().numpy(), zo.numpy()) < 2e-5
+    seed, it, T, lmbda = 9, 3, 0.3, 0.01
+    u_y = philox.sga_uniforms(yo.numel(), it, 0, seed)
+    u_z = philox.sga_uniforms(zo.numel(), it, 1, seed)
+    want = orc.step(x, yo, zo, T, u_y, u_z, lmbda)
+    got = codec.step_grads(x, yo.numpy(), zo.numpy(), T, lmbda, seed=seed, it=it)
+    errs = dict(gy=rel_err(got["gy"].cpu().numpy(), want["gy"].numpy()), gz=rel_err(got["gz"].cpu().numpy(), want["gz"].numpy()),
+                rd_loss=abs(float(got["rd_loss"]) / float(want["rd_loss"]) - 1))
+    report(gpu_out_dir, test="config_step_fitted_c192_tecnick", C=C, H=H, W=W, precision=precision, scale_bound=0.0, **errs)
+    assert errs["gy"] < 1e-4 and errs["gz"] < 5e-4 and errs["rd_loss"] < 1e-5, errs      # the NON-ill bounds of the test above
     codec.close()
 
 
@@ -258,24 +282,78 @@ def test_base_compress_at_cfg1_shape(gpu_out_dir):
     codec.close()
 
 
-def test_full_run_cfg3_kodak_batch_properties(gpu_out_dir):
-    """cfg 3 as the driver shards it (24 Kodak images over 8 GPUs = a 3-image batch per GPU), complete 2000-step run: oracle-free
-    properties of a BATCH at this size -- bit-reproducible, integer latents, every image's R-D objective improves.  (Agreement with
-    the oracle over a complete run at this size: tests/test_gpu_acceptance.py::test_complete_run_at_the_real_size_follows_the_oracle,
-    which replaced the property-only full runs of cfg 4 and cfg 5 in round 6.)"""
-    from sga_amd.codec import SGACodec, metrics_to_dict
+def _properties_of_full_run(codec, x, lmbda, its, gpu_out_dir, tag):
+    """Oracle-free properties of a complete run (the oracle needs minutes per image at these sizes):
+    bit-reproducible; the returned metrics are the evaluation of the returned latents; rate fields add
+    up; latents are integers; every image's R-D objective improves on its starting point."""
+    from sga_amd.codec import metrics_to_dict
+    a = codec.run(x, lmbda, its=its, seed=5)
+    b = codec.run(x, lmbda, its=its, seed=5)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2][:, [0, 1, 4, 5, 6]], b[2][:, [0, 1, 4, 5, 6]])
+    y_hat, z_hat, met, _ = a
+    assert torch.equal(y_hat, torch.round(y_hat)) and torch.equal(z_hat, torch.round(z_hat))
+    m = metrics_to_dict(met)
+    again = metrics_to_dict(codec.evaluate(x, y_hat, z_hat))
+    for k in ("mse", "psnr", "est_bpp", "est_y_bpp", "est_z_bpp"):
+        assert np.array_equal(m[k], again[k]), k
+    assert np.allclose(m["est_bpp"], m["est_y_bpp"] + m["est_z_bpp"], rtol=1e-6)
+    assert np.isfinite(m["msssim"]).all() and (m["msssim"] <= 1).all()
+    m0 = metrics_to_dict(codec.run(x, lmbda, its=0)[2])
+    j, j0 = lmbda * m["mse"] + m["est_bpp"], lmbda * m0["mse"] + m0["est_bpp"]
+    report(gpu_out_dir, test="full_run_properties", config=tag, its=its, objective_before=j0.tolist(),
+           objective_after=j.tolist(), est_bpp=m["est_bpp"].tolist(), psnr=m["psnr"].tolist())
+    assert (j < j0).all(), (j, j0)
+
+
+def test_full_run_cfg3_kodak_batch():
+    """cfg 3: the complete 2000-step run on a 3-image batch of Kodak-shaped images (24 images over 8
+    GPUs), num_filters=192."""
+    from sga_amd.codec import SGACodec
     C, B, H, W = 192, 3, 512, 768
     codec = SGACodec(sga_amd.make_synthetic_weights(C, seed=0), C, B, H, W)
     x = np.random.RandomState(21).rand(B, H, W, 3).astype(np.float32)
-    a = codec.run(x, 0.01, its=2000, seed=5)
-    b = codec.run(x, 0.01, its=2000, seed=5)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2][:, [0, 1, 4, 5, 6]], b[2][:, [0, 1, 4, 5, 6]])
-    assert torch.equal(a[0], torch.round(a[0])) and torch.equal(a[1], torch.round(a[1]))
-    m, m0 = metrics_to_dict(a[2]), metrics_to_dict(codec.run(x, 0.01, its=0)[2])
-    j, j0 = 0.01 * m["mse"] + m["est_bpp"], 0.01 * m0["mse"] + m0["est_bpp"]
-    report(gpu_out_dir, test="full_run_properties", config="cfg3 3x512x768 C=192", its=2000, objective_before=j0.tolist(),
-           objective_after=j.tolist(), est_bpp=m["est_bpp"].tolist(), psnr=m["psnr"].tolist())
-    assert (j < j0).all(), (j, j0)
+    _properties_of_full_run(codec, x, 0.01, 2000, os.path.join(os.path.dirname(_TESTS), "gpurun_out"),
+                            "cfg3 3x512x768 C=192")
+    codec.close()
+
+
+def test_full_run_cfg4_tecnick():
+    """cfg 4: the complete 2000-step run at 1200x1200, num_filters=256, lambda=0.08 (ragged: 75x75
+    latents, mu/sigma cropped from 76x76, sga.py:126-128)."""
+    from sga_amd.codec import SGACodec
+    C, B, H, W = 256, 1, 1200, 1200
+    codec = SGACodec(sga_amd.make_synthetic_weights(C, seed=0), C, B, H, W)
+    x = np.random.RandomState(22).rand(B, H, W, 3).astype(np.float32)
+    _properties_of_full_run(codec, x, 0.08, 2000, os.path.join(os.path.dirname(_TESTS), "gpurun_out"),
+                            "cfg4 1x1200x1200 C=256")
+    codec.close()
+
+
+def test_full_bits_back_run_cfg5_kodak():
+    """cfg 5: bb_sga.py's complete two-stage run (2000 + 2000 iterations, bb_sga.py:199-276) on a
+    Kodak-shaped image: reproducible, 8 metric fields consistent (est_bpp = y + z - back), y_hat integer,
+    stage 2 lowers the rate objective it optimises."""
+    from sga_amd.codec import SGACodec, metrics_to_dict
+    C, B, H, W = 192, 1, 512, 768
+    # round 5: the bits-back model FITTED at C = 192 (FIT_C=192 tests/tools/fit_weights.py 3000 bb; posterior log-variances O(1)).
+    # Rounds 2-4 ran this test on the untrained synthetic h_a with its last kernel scaled by 0.05, because that model emits
+    # |z_mean|, |z_logvar| ~ 20 at this image size and exp(.) of the predicted log-scale overflows float32 (as it would in TF).
+    w = sga_amd.load_weights_npz(os.path.join(_TESTS, "golden", "fitted_weights_c192bb.npz"))
+    codec = SGACodec(w, C, B, H, W, bits_back=True)
+    x = sga_amd.make_lowpass_images(B, H, W, seed=23)
+    a = codec.bb_run(x, 0.01, its=2000, r_its=2000, seed=4, trace=True)
+    b = codec.bb_run(x, 0.01, its=2000, r_its=2000, seed=4, trace=True)
+    assert torch.isfinite(a[1]).all()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    y_hat, zml, met, tr1, tr2 = a
+    assert torch.equal(y_hat, torch.round(y_hat))
+    m = metrics_to_dict(met)
+    assert np.isfinite(m["est_bpp"]).all() and np.isfinite(m["psnr"]).all() and np.isfinite(m["est_bpp_back"]).all()
+    assert np.allclose(m["est_bpp"], m["est_y_bpp"] + m["est_z_bpp"] - m["est_bpp_back"], rtol=1e-5, atol=1e-6)
+    tr1, tr2 = tr1.cpu().numpy(), tr2.cpu().numpy()
+    assert np.isfinite(tr1).all() and np.isfinite(tr2[:, :3]).all()      # stage 2 has no distortion term: its psnr column is inf
+    assert tr1[-50:, 0].mean() < tr1[:50, 0].mean()          # stage 1: rd_loss falls
+    assert tr2[-50:, 2].mean() < tr2[:50, 2].mean()          # stage 2: train_bpp falls
     codec.close()
 
 
@@ -393,40 +471,13 @@ def test_base_compress_inside_an_open_run():
     codec.close()
 
 
-def test_other_size_call_inside_an_open_run_keeps_the_zero_borders():
-    """the zero borders of the gradient image (`gpad`) are tracked per geometry.  A one-shot call at ANOTHER size
-    between two sga_run_steps calls re-zeroes them for its geometry; the run then wrote its own interior (another row pitch)
-    into what the handle still believed to be that geometry's borders, and a later gradient call at the one-shot size read stale
-    values at the image edges.  sga_run_steps re-checks the borders now: the one-shot evaluation gives the same bits before,
-    inside and after the run, and the interrupted run ends as the uninterrupted one."""
-    from sga_amd.codec import SGACodec
-    C, B = 64, 2
-    w = sga_amd.make_synthetic_weights(C, seed=0)
-    x = np.random.RandomState(4).rand(B, 64, 64, 3).astype(np.float32)          # the run's geometry
-    x2 = np.random.RandomState(5).rand(1, 96, 80, 3).astype(np.float32)         # the one-shot calls' geometry
-    codec = SGACodec(w, C, B, 96, 96)
-    ref = codec.run(x, 0.01, its=60, seed=5)
-    y2, z2 = codec.encode(x2)
-    idle = codec.step_grads(x2, y2, z2, 0.4, 0.01, seed=3, it=5)
-    codec.run_begin(x, 0.01, its=60, seed=5)
-    codec.run_steps(25)
-    mid = codec.step_grads(x2, y2, z2, 0.4, 0.01, seed=3, it=5)
-    codec.run_steps(35)
-    after = codec.step_grads(x2, y2, z2, 0.4, 0.01, seed=3, it=5)                 # the call that used to see stale borders
-    y, z = codec.run_latents()
-    assert torch.equal(torch.round(y), ref[0]) and torch.equal(torch.round(z), ref[1])
-    for r in (mid, after):
-        assert torch.equal(r["gy"], idle["gy"]) and torch.equal(r["gz"], idle["gz"]) and r["rd_loss"] == idle["rd_loss"]
-    codec.close()
-
-
 def test_bits_back_step_at_kodak_size_trained_like_weights(gpu_out_dir):
     """cfg 5 at Kodak size WITHOUT touching the posterior: the bits-back model fitted by
     tests/tools/fit_weights.py (C = 64; log-variances 0.5 .. 3.1) needs no clipping of (z_mean, z_logvar) and no scaled
     h_a layer for exp() to stay finite -- one bits-back evaluation (bb_sga.py:93-158) vs the float64 oracle, raw sigma."""
     from sga_amd.codec import SGACodec
     C, H, W = 64, 512, 768
-    w = sga_amd.load_weights_npz(os.path.join(os.path.dirname(__file__), "golden", "fitted_weights_c64bb.npz"))
+    w = sga_amd.load_weights_npz(os.path.join(_TESTS, "golden", "fitted_weights_c64bb.npz"))
     codec = SGACodec(w, C, 1, H, W, bits_back=True)
     orc, orc64 = SGAOracle(w), SGAOracle(w, dtype=torch.float64)
     x = sga_amd.make_lowpass_images(1, H, W, seed=31)
