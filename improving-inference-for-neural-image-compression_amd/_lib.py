@@ -16,9 +16,9 @@ LAB_LIB_PATH = os.path.join(_PKG_DIR, "libsga_hip_lab.so")
 # the run-time knobs the PRODUCT library reads from the environment; tests/test_host.py checks
 # the strings of the built library against this list
 PRODUCT_ENV_KNOBS = ("SGA_PRECISION", "SGA_NO_GRAPH", "SGA_NO_OVERLAP", "SGA_NO_SPLITK", "SGA_FORK_NAME", "SGA_FORK_VERBOSE",
-                     "SGA_PROFILE_BY_LAYER", "SGA_GRAPH_DROP", "SGA_X3_FORK", "SGA_X3_VARIANTS")
+                     "SGA_PROFILE_BY_LAYER", "SGA_X3_FORK", "SGA_X3_VARIANTS")
 
-SGA_ABI_VERSION = 5
+SGA_ABI_VERSION = 6
 
 STATUS = {
     0: "SGA_OK", -1: "SGA_ERR_BAD_ARG", -2: "SGA_ERR_BAD_SHAPE", -3: "SGA_ERR_UNSUPPORTED",
@@ -167,13 +167,13 @@ def load_library(path: str | None = None):
 
 class _CallLog:
     """Debugging aid (SGA_CALL_LOG=<file>): every C-ABI call of this process as one text line -- the entry point, then its
-    arguments in order: integers and floats by value, a handle as `h<n>` (n-th handle created), any other pointer as `P` / `0`
+    arguments in order: integers and floats by value, a handle as `h<n>` (n-th successful sga_create of the process, from 0), any other pointer as `P` / `0`
     (non-null / null), the members of sga_config for sga_create -- flushed BEFORE the call is made, so the last line of a
     crashed process is the call it died in.  `tests/c_client/sga_replay.cpp` replays such a file against the library from
     a process without Python or PyTorch (round 6: the hunt for the host SIGSEGV after mid-life hipGraphExecDestroy)."""
 
     def __init__(self, lib, path):
-        self._lib, self._f, self._handles = lib, open(path, "a"), {}
+        self._lib, self._f, self._handles, self._created = lib, open(path, "a"), {}, 0
 
     def _fmt(self, v):
         if isinstance(v, bool):
@@ -210,10 +210,11 @@ class _CallLog:
             self._f.write(line + "\n")
             self._f.flush()
             rc = fn(*args)
-            if name == "sga_create" and rc == 0:
-                self._handles[args[0]._obj.value] = len(self._handles)
+            if name == "sga_create" and rc == 0:      # h<n> = the n-th handle this process created (never reused)
+                self._handles[args[0]._obj.value] = self._created
+                self._created += 1
             if name == "sga_destroy":
-                self._handles = {k: v for k, v in self._handles.items() if "h%d" % v != line.split()[1]}
+                self._handles.pop(getattr(args[0], "value", None), None)
             return rc
         return call
 

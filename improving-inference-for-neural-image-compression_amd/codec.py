@@ -637,9 +637,9 @@ class SGACodec:
         return buf.value.decode()
 
     def counter(self, which: str) -> int:
-        """Graph-cache counters (sga_debug_counter): "captures", "cached", "evictions", "retired"."""
+        """Graph-cache counters (sga_debug_counter): "captures", "cached", "evictions", "dropped" (destroyed in mid-life)."""
         v = C.c_longlong(0)
-        idx = {"captures": 0, "cached": 1, "evictions": 2, "retired": 3}[which]
+        idx = {"captures": 0, "cached": 1, "evictions": 2, "dropped": 3}[which]
         self._chk(self.lib.sga_debug_counter(self.handle, idx, C.byref(v)), "sga_debug_counter")
         return int(v.value)
 

@@ -108,7 +108,7 @@ struct sga_handle {
   Buf* cur_part = nullptr;
   // hyper-prior branch runs on its own stream, forked/joined with events (also inside the graph)
   hipStream_t sB = nullptr;
-  // The stream every step GRAPH is captured and launched on: the library's own, HIGH priority (round 6).  Not for speed -- for the
+  // The stream every step GRAPH is captured and launched on: the library's own, LOW priority (round 6).  Not for speed -- for the
   // HIP runtime's Graph::UpdateStreams, which reads past the end of a graph's internal stream list when ALL of them share the
   // LAUNCH stream's hardware queue (host SIGSEGV inside hipGraphLaunch: "defect (a)" of rounds 3-5, root cause and stand-alone
   // reproducer in DESIGN_EXPERIMENTS.md A.13 / scripts/r06/graph_stream_collision_repro.hip).  The internal streams are created with
@@ -142,8 +142,6 @@ struct sga_handle {
   bool x3_variants = true;         // bf16x3 mode: 64- / 256-row tiles and the IGDN post-phase as in f32 mode (SGA_X3_VARIANTS=0: 128-row only)
   bool x3_fork = true;             // bf16x3 mode with the hyper branch on the second stream (round 4: on again, never forked at the
                                    //   graph's root -- synth_branch tick(); SGA_X3_FORK=0: single-stream as in rounds 2-3)
-  bool drop_destroy = false;       // drop_graph(): keep a dropped executable graph until sga_destroy (default, "retire") or destroy it at
-                                   //   once behind a synchronisation of both streams (SGA_GRAPH_DROP=destroy)
   // ---- keyed cache of LIVE executable graphs (round 5): one captured iteration per (kind, geometry, relaxation, sigma bound,
   // stamped) with its timed fork point.  A change of geometry / relaxation / bound SELECTS an entry -- nothing is dropped,
   // re-captured or re-timed when a shape comes back (a ragged last batch, a service alternating two sizes) -- and entries
@@ -162,9 +160,7 @@ struct sga_handle {
   unsigned long long graph_clock = 0;
   long long n_captures = 0;        // stream captures + instantiations so far (sga_debug_counter)
   long long n_graph_evictions = 0;
-  long long n_retired_destroyed = 0;            // retired graphs destroyed early because more than kMaxRetired had accumulated
-  std::vector<hipGraphExec_t> retired_graphs;   // candidate graphs that lost the timing: destroyed with the handle (experiment:
-                                   // destroying them while their sibling is in use crashed the process in the full test suite)
+  long long n_dropped = 0;         // executable graphs destroyed in mid-life so far (losing fork-point candidates, evictions, stamped graphs)
   int tuned_B = 0, tuned_H = 0, tuned_W = 0;   // geometry the last timed choice (tuned_name) was made for: graphs of that
   const char* tuned_name = nullptr;            // geometry built without timing (short runs, the stamped graph) reuse it
   int dbg_it = -1;                 // iteration being enqueued (SGA_DEBUG_DUMP)
@@ -1373,17 +1369,14 @@ int eval_impl(sga_handle* h, const Geom& g, const float* x, const float* y_hat, 
   return SGA_OK;
 }
 
-// Disposal of an executable graph that is dropped in mid-life (a losing fork-point candidate, a geometry change, a changed
-// sigma bound, the stamped graph of sga_profile_graph_*).  Default: RETIRED -- kept until sga_destroy (one small executable
-// graph per drop; base_compress no longer drops any).  SGA_GRAPH_DROP=destroy destroys it at once, behind a synchronisation of
-// the launching stream and of the handle's second stream.  Why not destroy by default: three full-suite runs of round 3 died
-// with a host SIGSEGV in the NEXT run on a handle after a mid-life hipGraphExecDestroy; round 4 hunted it (DESIGN_EXPERIMENTS.md
-// A.8a: freed-memory poisoning, a stand-alone HIP program with the same life cycle incl. destruction with replays in flight,
-// a lifetime audit of everything a node references) without finding a host-side cause, and under the destroy policy the full
-// suite passed 2 of 3 times and crashed once at the round-3 spot (second 2000-iteration run at 1200 x 1200, C = 256); under
-// the retire policy it has never crashed (9 full runs over two rounds).
-constexpr size_t kMaxRetired = 256;
-
+// Disposal of an executable graph that is dropped in mid-life (a losing fork-point candidate, the least recently used entry of a
+// full cache, the stamped graph of sga_profile_graph_*): destroyed at once, behind a synchronisation of the streams its replays
+// ran on.  Rounds 3-5 RETIRED such graphs until sga_destroy instead, because mid-life destruction was followed -- in long
+// processes, never in a short one -- by a host SIGSEGV inside a later hipGraphLaunch.  Round 6 found why (DESIGN_EXPERIMENTS.md
+// A.13): not the destruction, but what it does to the hardware queues' reference counts -- the HIP runtime's
+// Graph::UpdateStreams overruns a graph's internal stream list when all of them share the LAUNCH stream's hardware queue, and
+// destroying streams is what makes two consecutive stream creations land on one queue.  Graphs are launched on a stream of
+// another priority class now (sga_handle::sG), which can share no queue with them; the retire list is gone.
 // The calls that replay step graphs run on the handle's own launch stream (sga_handle::sG): ordered after everything the caller
 // has enqueued on ITS stream so far, and the caller's stream ordered after them on the way out -- also on an error return.
 struct LaunchStream {
@@ -1401,28 +1394,11 @@ struct LaunchStream {
 
 void drop_graph(sga_handle* h, hipGraphExec_t& ex, hipStream_t st = nullptr) {
   if (!ex) return;
-  if (h->drop_destroy) {
-    if (st) (void)hipStreamSynchronize(st);
-    if (h->sG) (void)hipStreamSynchronize(h->sG);      // (callers without a stream: sga_profile_graph_begin / _end)
-    if (h->sB) (void)hipStreamSynchronize(h->sB);
-    (void)hipGraphExecDestroy(ex);
-  } else {
-    h->retired_graphs.push_back(ex);
-    // The retire policy must not be an unbounded leak either: a service that cycles through more keys than the cache holds
-    // retires three graphs per miss (round 5 soak: 1 928 retired graphs after 648 runs).  Past kMaxRetired the OLDEST half is
-    // destroyed behind a synchronisation of both streams -- graphs that were last replayed hundreds of launches ago, not the
-    // sibling of a graph in use, which is where the round-3 / round-4 crashes sat (and 1 872 immediate mid-life destroys in the
-    // same soak under SGA_GRAPH_DROP=destroy did not crash either: profiles/r05_soak_evictions.txt).
-    if (h->retired_graphs.size() > kMaxRetired) {
-      if (st) (void)hipStreamSynchronize(st);
-      if (h->sG) (void)hipStreamSynchronize(h->sG);
-      if (h->sB) (void)hipStreamSynchronize(h->sB);
-      const size_t n = h->retired_graphs.size() / 2;
-      for (size_t i = 0; i < n; ++i) (void)hipGraphExecDestroy(h->retired_graphs[i]);
-      h->retired_graphs.erase(h->retired_graphs.begin(), h->retired_graphs.begin() + (long)n);
-      h->n_retired_destroyed += (long long)n;
-    }
-  }
+  if (st) (void)hipStreamSynchronize(st);
+  if (h->sG) (void)hipStreamSynchronize(h->sG);      // (callers without a stream: sga_profile_graph_begin / _end)
+  if (h->sB) (void)hipStreamSynchronize(h->sB);
+  (void)hipGraphExecDestroy(ex);
+  ++h->n_dropped;
   ex = nullptr;
 }
 
@@ -1466,7 +1442,7 @@ void erase_graph(sga_handle* h, sga_handle::GraphEntry* e, hipStream_t st) {
 
 // The fork point of the hyper branch, chosen by time: captures one step graph per candidate (`capture` records
 // one iteration under the current h->fork_name), replays each a few times -- on the caller's live state: the replays are
-// iterations of the run and are counted in *done -- and returns the fastest; the others are retired (sga_handle::retired_graphs).
+// iterations of the run and are counted in *done -- and returns the fastest; the others are destroyed (drop_graph).
 template <typename Cap>
 int timed_fork_choice(sga_handle* h, hipStream_t st, int B, int H, int W, Cap&& capture, hipGraphExec_t* out, int* done) {
   constexpr int kTuneReps = 8;
@@ -1501,8 +1477,6 @@ int timed_fork_choice(sga_handle* h, hipStream_t st, int B, int H, int W, Cap&& 
     if (verbose)
       fprintf(stderr, "sga fork point %-8s B=%d %dx%d: %.1f us per iteration\n", cands[c] ? cands[c] : "start", B, H, W,
               ms * 1000.f / kTuneReps);
-    // the losing candidates are kept until the handle goes (two small executable graphs per tuned geometry): see
-    // sga_handle::retired_graphs
     if (!best || ms < best_ms) {
       drop_graph(h, best, st);
       best = ex; best_ms = ms; best_name = cands[c];
@@ -1521,7 +1495,6 @@ int timed_fork_choice(sga_handle* h, hipStream_t st, int B, int H, int W, Cap&& 
 void free_all(sga_handle* h) {
   for (auto& e : h->graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
   h->graphs.clear();
-  for (hipGraphExec_t gx : h->retired_graphs) (void)hipGraphExecDestroy(gx);
   if (h->graph_main) (void)hipGraphExecDestroy(h->graph_main);
   for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   if (h->ev_fork2_cap) (void)hipEventDestroy(h->ev_fork2_cap);
@@ -1794,9 +1767,14 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
     // (hardware-queue priorities act on eager streams; graph nodes ignore them)
     if (const char* hy = LAB_ENV("SGA_HYBRID")) h->side_hybrid = hy[0] == '1';
     {
-      const char* ls = LAB_ENV("SGA_LAUNCH_STREAM");      // laboratory: "caller" = rounds 1-5 (graphs on the caller's stream), "low" = the other class
-      const bool own = !(ls && strcmp(ls, "caller") == 0);
-      if (own && (hipStreamCreateWithPriority(&h->sG, hipStreamNonBlocking, (ls && strcmp(ls, "low") == 0) ? lo : hi) != hipSuccess ||
+      // LOW priority (numerically greatest): measured at cfg 2, the iteration takes 1773-1778 us on a low-priority launch stream,
+      // 1773-1775 on the caller's normal one and 1806-1816 on a HIGH-priority one (the hyper branch's kernels, on the graph's
+      // normal-priority internal stream, then lose every dispatch arbitration and become the critical path);
+      // profiles/r06_launch_stream_priority.txt.  Laboratory: SGA_LAUNCH_STREAM=caller (rounds 1-5: graphs on the caller's stream) | high
+      const char* ls = LAB_ENV("SGA_LAUNCH_STREAM");
+      const int want = (ls && strcmp(ls, "high") == 0) ? hi : (lo != 0 ? lo : hi);
+      const bool own = !(ls && strcmp(ls, "caller") == 0) && want != 0;      // (a device without stream priorities: the caller's stream)
+      if (own && (hipStreamCreateWithPriority(&h->sG, hipStreamNonBlocking, want) != hipSuccess ||
                   hipEventCreateWithFlags(&h->ev_in, evflags) != hipSuccess || hipEventCreateWithFlags(&h->ev_out, evflags) != hipSuccess))
         return fail(SGA_ERR_HIP);
     }
@@ -1823,8 +1801,6 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   }
   env = getenv("SGA_X3_FORK");
   h->x3_fork = !(env && env[0] == '0');
-  env = getenv("SGA_GRAPH_DROP");
-  if (env) h->drop_destroy = strcmp(env, "destroy") == 0;
   env = LAB_ENV("SGA_SPLIT256");
   h->split256 = !(env && env[0] == '0');
   env = LAB_ENV("SGA_BM256");
@@ -2541,7 +2517,7 @@ int sga_debug_counter(const sga_handle* h, int which, long long* value) {
     case SGA_COUNTER_GRAPH_CAPTURES: *value = h->n_captures; return SGA_OK;
     case SGA_COUNTER_GRAPHS_CACHED: *value = (long long)h->graphs.size(); return SGA_OK;
     case SGA_COUNTER_GRAPH_EVICTIONS: *value = h->n_graph_evictions; return SGA_OK;
-    case SGA_COUNTER_GRAPHS_RETIRED: *value = (long long)h->retired_graphs.size(); return SGA_OK;
+    case SGA_COUNTER_GRAPHS_DROPPED: *value = h->n_dropped; return SGA_OK;
   }
   return SGA_ERR_BAD_ARG;
 }

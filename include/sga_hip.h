@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGA_ABI_VERSION 5
+#define SGA_ABI_VERSION 6
 
 typedef enum sga_status {
   SGA_OK = 0,
@@ -366,8 +366,8 @@ int sga_get_fork_point(const sga_handle* h, char* name, int name_len);
 typedef enum sga_counter {
   SGA_COUNTER_GRAPH_CAPTURES = 0,   /* stream captures + instantiations so far (3 per timed geometry, 1 per untimed one) */
   SGA_COUNTER_GRAPHS_CACHED = 1,    /* live entries */
-  SGA_COUNTER_GRAPH_EVICTIONS = 2,  /* entries retired because the cache was full (16) */
-  SGA_COUNTER_GRAPHS_RETIRED = 3    /* dropped executable graphs kept alive (losing fork-point candidates, evictions): until sga_destroy, or until 256 have accumulated (then the oldest half is destroyed) */
+  SGA_COUNTER_GRAPH_EVICTIONS = 2,  /* entries dropped because the cache was full (16) */
+  SGA_COUNTER_GRAPHS_DROPPED = 3    /* executable graphs destroyed in mid-life so far: losing fork-point candidates (two per timed geometry), evictions, stamped graphs (ABI 6; ABI 4-5: graphs retired until sga_destroy) */
 } sga_counter;
 int sga_debug_counter(const sga_handle* h, int which, long long* value);
 

@@ -7,7 +7,7 @@
 #  F  destroy policy under MALLOC_CHECK_=3 HSA_ENABLE_INTERRUPT=0
 set -u
 cd "$GRAFT_REPO_ROOT"; OUT=$PWD/gpurun_out/r06_s03; mkdir -p $OUT
-T=scripts/r06/defect_a_repro/test_gpu_configs_r05.py      # tests/test_gpu_configs.py as of round 5: the 100-second reproducer
+T=tests/repro/defect_a_configs_r05_frozen.py      # tests/test_gpu_configs.py as of round 5: the 100-second reproducer
 LAB=$PWD/improving-inference-for-neural-image-compression_amd/libsga_hip_lab.so
 run() { local n=$1; shift; ( "$@" ) > $OUT/$n.log 2>&1; echo "=== $n rc $?"; tail -2 $OUT/$n.log | cut -c1-200; }
 run B env SGA_LIB=$LAB SGA_DEBUG_SEGV=$OUT/B_segv.txt SGA_CALL_LOG=$OUT/B_calls.txt SGA_GRAPH_DROP=destroy timeout 420 python -m pytest $T -q -x -p no:cacheprovider

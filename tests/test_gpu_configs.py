@@ -308,8 +308,9 @@ def test_base_compress_between_runs_leaves_the_step_graph_alone():
 def test_graph_cache_selects_instead_of_recapturing():
     """the handle keeps one executable step graph per (geometry, relaxation, sigma bound) with its timed fork
     point.  Alternating three geometries (a ragged last batch, a service with two image sizes), toggling the sigma bound and
-    the relaxation: after the first pass NOTHING is captured again, nothing is retired, and every run is bit-identical to
-    the first run of its kind."""
+    the relaxation: after the first pass NOTHING is captured again, nothing more is dropped, and every run is bit-identical to
+    the first run of its kind.  (Round 6: the losing fork-point candidates are DESTROYED at once -- counter "dropped" -- since
+    graphs run on the library's own launch stream; rounds 3-5 retired them until sga_destroy.)"""
     from sga_amd.codec import SGACodec
     C = 64
     w = sga_amd.make_synthetic_weights(C, seed=0)
@@ -318,14 +319,14 @@ def test_graph_cache_selects_instead_of_recapturing():
     xs = [np.random.RandomState(10 + i).rand(b, hh, ww, 3).astype(np.float32) for i, (b, hh, ww) in enumerate(geos)]
     first = [codec.run(x, 0.01, its=110, seed=3) for x in xs]          # >= 100 iterations: three candidates timed per geometry
     assert codec.counter("captures") == 9 and codec.counter("cached") == 3
-    retired = codec.counter("retired")                                 # the losing candidates (kept until sga_destroy)
-    assert retired == 6
+    dropped = codec.counter("dropped")                                 # the losing candidates: two per timed geometry
+    assert dropped == 6
     for rnd in range(20):
         for x, ref in zip(xs, first):
             out = codec.run(x, 0.01, its=110 if rnd == 0 else 12, seed=3)
             if rnd == 0:
                 assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
-    assert codec.counter("captures") == 9 and codec.counter("cached") == 3 and codec.counter("retired") == retired
+    assert codec.counter("captures") == 9 and codec.counter("cached") == 3 and codec.counter("dropped") == dropped
     # the sigma bound and the relaxation are part of the key: a new value captures ONE more graph (it inherits the
     # geometry's timed fork point), coming back to the old value captures nothing
     fp = codec.fork_point()
@@ -353,8 +354,8 @@ def test_graph_cache_selects_instead_of_recapturing():
 
 
 def test_graph_cache_eviction_keeps_results():
-    """More distinct keys than the cache holds (16): the least recently used entries are retired (kept until sga_destroy under the
-    default policy), and a retired key that comes back is simply captured again -- every run stays bit-identical to its first."""
+    """More distinct keys than the cache holds (16): the least recently used entries are destroyed, and a dropped key that comes
+    back is simply captured again -- every run stays bit-identical to its first."""
     from sga_amd.codec import SGACodec
     C = 64
     w = sga_amd.make_synthetic_weights(C, seed=0)
@@ -367,7 +368,7 @@ def test_graph_cache_eviction_keeps_results():
     for a, b in zip(first, again):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert codec.counter("cached") == 16 and codec.counter("evictions") >= 4
-    assert codec.counter("retired") == codec.counter("evictions")        # short runs: no fork-point candidates were timed
+    assert codec.counter("dropped") == codec.counter("evictions")        # short runs: no fork-point candidates were timed
     codec.close()
 
 
