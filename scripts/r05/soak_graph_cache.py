@@ -38,9 +38,9 @@ while time.time() - t0 < 60 * MINUTES:
         runs += 1
     if captures_after_first_pass is None:
         captures_after_first_pass = codec.counter("captures")
-    say("%.0f s: %d complete runs, captures %d (after the first pass: %d), cached %d, evictions %d, retired %d, mismatches %d" %
+    say("%.0f s: %d complete runs, captures %d (after the first pass: %d), cached %d, evictions %d, dropped %d, mismatches %d" %
         (time.time() - t0, runs, codec.counter("captures"), captures_after_first_pass, codec.counter("cached"),
-         codec.counter("evictions"), codec.counter("retired"), mism))
+         codec.counter("evictions"), codec.counter("dropped"), mism))
 codec.set_relaxation("sga", "exp0")
 say("soak (%s): %d complete 2000-iteration runs on one handle over %d (geometry, relaxation, bound) keys in %.0f s; repeats bit-equal: %s; "
     "captures after the first pass: %d" % (PRECISION, runs, len(plan), time.time() - t0, mism == 0, codec.counter("captures") - captures_after_first_pass))
