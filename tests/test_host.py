@@ -134,6 +134,19 @@ def test_header_is_plain_c_and_client_compiles(tmp_path):
                     "-lamdhip64", f"-Wl,-rpath,{PKG}:{os.path.join(rocm, 'lib')}"], check=True)
 
 
+def test_replay_client_compiles(tmp_path):
+    """tests/c_client/sga_replay.cpp (round 6: replays a recorded C-ABI call log without Python / PyTorch in the process) builds
+    against the header with plain g++ and the HIP runtime API headers; it dlopens the library at run time."""
+    import subprocess
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.join(rocm, "include"), os.path.join(ROOT, "tests", "c_client", "sga_replay.cpp"),
+                    "-o", str(tmp_path / "replay"), "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-ldl",
+                    f"-Wl,-rpath,{os.path.join(rocm, 'lib')}"], check=True)
+    r = subprocess.run([str(tmp_path / "replay")], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load_library(str(tmp_path / "libsga_hip.so"))
@@ -376,3 +389,39 @@ def _worker_patched(rank, world, port, X, out_dir, bs):
     d.eval_batch_num_pixels = bs * PIX
     globals()["driver"] = d
     _worker(rank, world, port, X, out_dir, bs)
+
+
+def test_call_log_numbers_handles_by_creation_and_never_reuses_an_id(tmp_path):
+    """SGA_CALL_LOG (round 6; the input of tests/c_client/sga_replay.cpp): one line per C-ABI call, scalars by value, pointers as
+    P / 0, a handle as h<n> = the n-th successful sga_create of the process -- also after earlier handles were destroyed (the
+    first version reused ids, which made a recorded log ambiguous)."""
+    import ctypes as C
+
+    class Fake:
+        def __init__(self):
+            self.next = 0x1000
+
+        def __getattr__(self, name):
+            def f(*a):
+                if name == "sga_create":
+                    self.next += 0x100
+                    a[0]._obj.value = self.next
+                return 0
+            return f
+
+    path = str(tmp_path / "calls.txt")
+    log = _lib._CallLog(Fake(), path)
+    cfg, w = _lib.SgaConfig(192, 1, 512, 768, 0, 1, 0.0, 0), _lib.SgaWeights()
+    hs = [C.c_void_p(0) for _ in range(3)]
+    log.sga_create(C.byref(hs[0]), C.byref(cfg), C.byref(w))
+    log.sga_create(C.byref(hs[1]), C.byref(cfg), C.byref(w))
+    log.sga_destroy(hs[0])
+    log.sga_create(C.byref(hs[2]), C.byref(cfg), C.byref(w))          # the third handle is h2, not a recycled h0 / h1
+    log.sga_run(hs[2], C.c_void_p(5), 1, 512, 768, 0.01, 1.0, 2000, 0.005, 1e-3, 700, 0.5, 5, None, None, C.c_void_p(7), C.c_void_p(8),
+                C.c_void_p(9), None, C.c_void_p(77))
+    log.sga_run_steps(hs[1], 10, C.c_void_p(77))
+    lines = open(path).read().splitlines()
+    assert lines[0] == "sga_create 192 1 512 768 0 1 0.0" and lines[2] == "sga_destroy h0"
+    assert lines[4] == "sga_run h2 P 1 512 768 0.01 1.0 2000 0.005 0.001 700 0.5 5 0 0 P P P 0 P"
+    assert lines[5] == "sga_run_steps h1 10 P"
+
