@@ -306,7 +306,8 @@ def test_trace_2000_at_the_production_schedule(gpu_out_dir, precision, golden):
         # shows at once) and to 1e-4 over the first 25; a sanity bound afterwards; the north-star tolerance itself at the end.
         assert (rel[:10, :3] < 1e-5).all() and (rel[:25, :3] < 1e-4).all(), rep
         assert (rel[:, :3] < 3e-2).all() and (np.abs(got[:, 3] - want[:, 3]) < 0.06).all(), rep
-        assert (win_rel < 1.5e-2).all(), rep          # ... and the 100-iteration window means stay together all the way (round 6)
+        assert (win_rel < 4e-3).all(), rep          # ... and the 100-iteration window means stay together all the way (round 6;
+                                                   # measured 1.0e-3 / 4.6e-4 / 9.7e-4 in f32 / bf16x3 / bf16x2, pointwise up to 1 %)
         assert abs(rep["end_d_bpp_mean"]) < TOL_BPP and abs(rep["end_d_psnr_mean"]) < TOL_PSNR, rep
     else:
         assert (rel[:300, :3] < 1e-4).all(), rep
@@ -390,7 +391,7 @@ def test_complete_run_at_the_real_size_follows_the_oracle(gpu_out_dir, name):
     assert want[-1, 0] < want[0, 0]                                  # the run optimises
     assert (rel[:10, :3] < 1e-5).all() and (rel[:25, :3] < 1e-4).all(), rep
     assert (rel[:, :3] < 3e-2).all() and (np.abs(got[:, 3] - want[:, 3]) < 0.06).all(), rep
-    assert (win_rel < 1e-2).all(), rep
+    assert (win_rel < 4e-3).all(), rep          # measured: 1.1e-3 (cfg 3), 3.8e-4 (cfg 4), 1.5e-3 (cfg 5); runs are bit-reproducible
     assert abs(rep["end_d_bpp"]) < TOL_BPP and abs(rep["end_d_psnr"]) < TOL_PSNR, rep
     if bb:
         assert abs(rep["end_d_bpp_back"]) < TOL_BPP and rep["stage2_max_rel_all"] < 3e-2, rep
