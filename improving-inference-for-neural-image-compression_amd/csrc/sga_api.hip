@@ -185,7 +185,13 @@ struct sga_handle {
 
   int fork_delay_us = 0;           // SGA_FORK_DELAY_US (experiment)
   bool in_hyper = false;           // the launches being enqueued belong to the hyper branch
-  int side_target = 384;           // split-K target (workgroups per launch) of the hyper branch (SGA_SIDE_TARGET; 0: the main chain's 512)
+  int side_target = 256;           // split-K target (workgroups per launch) of the hyper branch when it runs BESIDE the synthesis chain
+                                   //   (SGA_SIDE_TARGET; 0: the main chain's 512).  Round 6: 256, was 384 -- with the main chain on the
+                                   //   low-priority launch stream the branch's kernels win the dispatch arbitration, and one workgroup per CU
+                                   //   disturbs igdn2.bwd / gs2.bwd / igdn1.bwd less: cfg 2 -7.6 us per iteration (5 of 5 A/B rounds), B = 1 +1.5 %,
+                                   //   B = 32 +0.6 %, Kodak / Tecnick sizes within +-0.2 % (profiles/r06_side_target.txt)
+  int side_target_alone = 384;     // ... and when the branch is ALL that runs (bits-back stage 2, bb_sga.py:239-261: 0.495 against 0.570 ms)
+  bool hyper_alone = false;        // rd_forward_backward without the synthesis chain
   bool side_last = true;           // graph capture: create the hyper branch's nodes after the main chain's (SGA_SIDE_LAST=0: before)
   int relax = 0, sched = 0;        // sga_set_relaxation
   int use_graph = 1;
@@ -357,7 +363,7 @@ int pick_ksplit(const sga_handle* h, ConvArgs& a) {
   // lose with that target and keep 512; profiles/r04_b1_split_targets_by_layer.txt)
   static const int small_tiles = LAB_ENV("SGA_SMALL_TILES") ? atoi(LAB_ENV("SGA_SMALL_TILES")) : 64;      // 0: rule off (experiments)
   if (a.bm != 256 && blocks <= small_tiles) target = 256;
-  if (h->in_hyper && h->side_target > 0) target = h->side_target;   // hyper branch (whichever stream it runs on: the
+  if (h->in_hyper && h->side_target > 0) target = h->hyper_alone ? h->side_target_alone : h->side_target;   // hyper branch (whichever stream it runs on: the
                                                                      // split decides the summation order, i.e. result bits)
   const int bn = a.Npad / a.ntiles_n;
   const bool big = blocks > 256 || (blocks == 256 && a.nphase == 1 && !h->split256);
@@ -1262,6 +1268,7 @@ int rd_forward_backward(sga_handle* h, const Geom& g, const float* x, bool with_
     h->cur_part = &h->part;
     return rc;
   }
+  h->hyper_alone = !do_synth;
   const bool fork = h->overlap && (!h->x3 || h->x3_fork) && !h->profiling && do_synth;
   if (!fork) {
     h->cur_part = &h->part;
@@ -1818,7 +1825,7 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
   env = LAB_ENV("SGA_SIDE_LAST");
   if (env) h->side_last = env[0] == '1';
   env = LAB_ENV("SGA_SIDE_TARGET");
-  if (env) h->side_target = atoi(env);
+  if (env) h->side_target = h->side_target_alone = atoi(env);
   env = LAB_ENV("SGA_FUSED_GDN");
   h->fused_gdn = !(env && env[0] == '0');
   // gdn_fused.hip has instances for C / 32 in {2, 4, 6, 8}; wider models (num_filters = 320, 384, ...) take the generic
