@@ -189,8 +189,12 @@ def test_step_across_launch_plans(C, B, H, W, gpu_out_dir, monkeypatch):
             if ez[b] < max(1e-4, 3 * f32_gz[b]):
                 continue
             # ... or an h_s ReLU unit of this image within float32 noise of its kink was switched the other way by the
-            # summation order: bounded (one unit carries < 0.5 % of a gradient) and local (its receptive field in z)
-            assert kink[b] < 3e-5 and ez[b] < 5e-3 and (dz[b] > 1e-4).mean() < 0.03, (precision, b, ez.tolist(), kink.tolist())
+            # summation order: bounded (one unit carries < 0.5 % of a gradient) and local (its receptive field in z: fewer than
+            # 3 % of the image's elements -- or, on a small latent grid, fewer than 1.5 C of them: the unit's own z position across
+            # the channels.  Round 6: at (192, 5, 192, 320), z = 3 x 5 positions, the unit of image 2 at 3.4e-7 of its kink flipped
+            # when the hyper branch's split-K target went from 384 to 256: 191 of 2 880 elements, max 2.1e-3)
+            n_off = int((dz[b] > 1e-4).sum())
+            assert kink[b] < 3e-5 and ez[b] < 5e-3 and n_off < max(0.03 * dz[b].size, 1.5 * C), (precision, b, n_off, ez.tolist(), kink.tolist())
         a = codec.run(x, lmbda, its=12, t0=4, annealing_rate=0.05, seed=3)
         b = codec.run(x, lmbda, its=12, t0=4, annealing_rate=0.05, seed=3)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), precision
