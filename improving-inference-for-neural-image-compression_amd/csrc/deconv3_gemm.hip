@@ -191,159 +191,6 @@ __global__ __launch_bounds__(256) void deconv3_col2im_kernel(const float* __rest
   }
 }
 
-// ---- the two kernels above as ONE launch (round 6, VERDICT r5 #4c; laboratory: SGA_GS3_FUSED=1) ---------------------------------
-// A workgroup owns FT x FT input positions = a (2 FT) x (2 FT) block of output pixels.  It forms the products P of its positions
-// AND of their 1-wide halo -- (FT + 2)^2 = 324 rows, the same MFMA sequence per 16-row block as deconv3_gemm_kernel, so the same
-// bits -- straight into LDS ([324][76] floats = 98.5 KB beside the 64-KB weight matrix: one workgroup per CU), then sums the 9 / 6 / 6
-// / 4 products of every output pixel out of LDS in deconv3_col2im_kernel's fixed order, with the distortion in the epilogue.  P
-// never goes to HBM (2 x 42 MB at cfg 2) and the layer is one launch; the price is the halo, recomputed: 324 / 256 = 1.27 x the
-// GEMM's MFMA work.  Seven waves, three row blocks each (21 x 16 = 336 >= 324).  C <= 192 (the weights must fit beside the tile).
-constexpr int FT = 16, FH = FT + 2, FPOS = FH * FH, FNT = 448, FNW = FNT / 64, FRB = (FPOS + 15) / 16;
-static_assert(FRB % FNW == 0, "row blocks per wave");
-template <int CQ, bool MSE>
-__global__ __launch_bounds__(FNT, 2) void deconv3_fused_kernel(const float* __restrict__ in, const float* __restrict__ w /*[80][C]*/,
-                                                               const float* __restrict__ bias, float* __restrict__ out, int Hi, int Wi,
-                                                               int Ho, int Wo, int tiles_x, Col2imMse ms) {
-  constexpr int C = CQ * 16, PITCH = C + 8;
-  extern __shared__ __attribute__((aligned(16))) float Fs[];      // [80][PITCH] weights, then [FPOS][CPITCH] products
-  float* const Bs = Fs;
-  float* const Ps = Fs + NCOL * PITCH;
-  __shared__ double red[2 * FNW];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int b = blockIdx.y;
-  const int ty0 = (blockIdx.x / tiles_x) * FT, tx0 = (blockIdx.x % tiles_x) * FT;
-  for (int f = tid; f < NCOL * (C / 4); f += FNT) {
-    const int n = f / (C / 4), c4 = f - n * (C / 4);
-    *reinterpret_cast<f32x4*>(&Bs[n * PITCH + c4 * 4]) = *reinterpret_cast<const f32x4*>(w + (size_t)n * C + c4 * 4);
-  }
-  const int li = lane & 15, g = lane >> 4;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  auto load_rows = [&](int rb, f32x4 (&dst)[CQ]) {      // the 16 halo positions of row block rb: this lane's k-slices of position rb * 16 + li
-    const int pos = rb * 16 + li;
-    const int i = ty0 + pos / FH - 1, j = tx0 + pos % FH - 1;
-    const bool ok = pos < FPOS && (unsigned)i < (unsigned)Hi && (unsigned)j < (unsigned)Wi;
-    const float* src = in + ((size_t)(b * Hi + (ok ? i : 0)) * Wi + (ok ? j : 0)) * C + g * 4;
-#pragma unroll
-    for (int q = 0; q < CQ; ++q) dst[q] = ok ? *reinterpret_cast<const f32x4*>(src + q * 16) : zero4;
-  };
-  f32x4 a_cur[CQ], a_nxt[CQ];
-  load_rows(wid, a_cur);
-  __syncthreads();                                         // the weights are in LDS
-#pragma unroll 1
-  for (int k = 0; k < FRB / FNW; ++k) {
-    const int rb = wid + k * FNW;
-    if (k + 1 < FRB / FNW) load_rows(rb + FNW, a_nxt);     // the next row block's rows arrive while this one is multiplied
-    asm volatile("" ::: "memory");                         // (keeps the weight fragments in LDS: see deconv3_gemm_kernel)
-    f32x4 acc[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) acc[cb] = zero4;
-#pragma unroll
-    for (int q = 0; q < CQ; ++q) {
-      f32x4 bf[NCB];
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
-        bf[cb] = *reinterpret_cast<const f32x4*>(&Bs[(cb * 16 + li) * PITCH + q * 16 + g * 4]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[cb][r], a_cur[q][r], acc[cb], 0, 0, 0);
-    }
-    const int pos = rb * 16 + li;
-    if (pos < FPOS) {
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
-        if (cb * 16 + 4 * g < CPITCH) *reinterpret_cast<f32x4*>(&Ps[pos * CPITCH + cb * 16 + 4 * g]) = acc[cb];      // columns 76..79 are padding
-    }
-    if (k + 1 < FRB / FNW) {
-#pragma unroll
-      for (int q = 0; q < CQ; ++q) a_cur[q] = a_nxt[q];
-    }
-  }
-  __syncthreads();
-  // ---- col2im out of LDS: deconv3_col2im_kernel's loop with an FH-wide halo grid ----
-  float a0 = 0.f, a1 = 0.f, coef = 0.f;
-  if constexpr (MSE) {
-    if (ms.ctx->lambda > 0.f) coef = ms.ctx->lambda * 2.0f * 65025.0f * ms.ctx->loss_scale / (float)(Ho * Wo * 3);
-  }
-  const float bz[3] = {bias ? bias[0] : 0.f, bias ? bias[1] : 0.f, bias ? bias[2] : 0.f};
-  for (int q = tid; q < 4 * FT * FT; q += FNT) {
-    const int ly = q / (2 * FT), lx = q - ly * (2 * FT);
-    const int oy = 2 * ty0 + ly, ox = 2 * tx0 + lx;
-    if (oy >= Ho || ox >= Wo) continue;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const int ky = (ly & 1) + 2 * a;
-      if (ky > 4) continue;
-      const int hy = ((ly - ky + 2) >> 1) + 1;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int kx = (lx & 1) + 2 * c;
-        if (kx > 4) continue;
-        const int hx = ((lx - kx + 2) >> 1) + 1;
-        const float* t = &Ps[(hy * FH + hx) * CPITCH + (ky * 5 + kx) * 3];
-        s0 += t[0]; s1 += t[1]; s2 += t[2];
-      }
-    }
-    const float tv[3] = {s0 + bz[0], s1 + bz[1], s2 + bz[2]};
-    const size_t idx = (((size_t)b * Ho + oy) * Wo + ox) * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      out[idx + c] = tv[c];
-      if constexpr (MSE) {
-        const float xv = ms.x[idx + c];
-        const float d = xv - tv[c];
-        a0 += d * d;
-        const float qv = rintf(fminf(fmaxf(tv[c], 0.f), 1.f) * 255.0f);
-        const float dq = xv * 255.0f - qv;
-        a1 += dq * dq;
-        ms.gpad[((size_t)(b * ms.Hp + oy + 2) * ms.Wp + ox + 2) * 3 + c] = coef * (tv[c] - xv);
-      }
-    }
-  }
-  if constexpr (MSE) {
-    double d0 = (double)a0, d1 = (double)a1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      d0 += __shfl_down(d0, o, 64);
-      d1 += __shfl_down(d1, o, 64);
-    }
-    if (lane == 0) { red[wid] = d0; red[FNW + wid] = d1; }
-    __syncthreads();
-    if (tid == 0) {
-      double t0 = 0.0, t1 = 0.0;
-      for (int k = 0; k < FNW; ++k) { t0 += red[k]; t1 += red[FNW + k]; }
-      atomicAdd(&ms.sums[b].sq_p[blockIdx.x % kSqSlots], t0);
-      atomicAdd(&ms.sums[b].sqq_p[blockIdx.x % kSqSlots], t1);
-    }
-  }
-}
-
-template <int CQ>
-int launch_fused(const float* in, const float* w, const float* bias, float* out, int B, int Hi, int Wi, int Ho, int Wo,
-                 const float* x, const StepCtx* ctx, ImgSums* sums, float* gpad, int Hp, int Wp, hipStream_t s) {
-  constexpr int C = CQ * 16;
-  const size_t lds = ((size_t)NCOL * (C + 8) + (size_t)FPOS * CPITCH) * sizeof(float);
-  static std::atomic<unsigned long long> attr_devs{0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3_fused_kernel<CQ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&deconv3_fused_kernel<CQ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_devs.fetch_or(bit, std::memory_order_release);
-  }
-  const int tiles_x = (Wi + FT - 1) / FT, tiles_y = (Hi + FT - 1) / FT;
-  if (x)
-    hipLaunchKernelGGL((deconv3_fused_kernel<CQ, true>), dim3(tiles_x * tiles_y, B), dim3(FNT), lds, s, in, w, bias, out, Hi, Wi, Ho, Wo,
-                       tiles_x, Col2imMse{x, ctx, sums, gpad, Hp, Wp});
-  else
-    hipLaunchKernelGGL((deconv3_fused_kernel<CQ, false>), dim3(tiles_x * tiles_y, B), dim3(FNT), lds, s, in, w, bias, out, Hi, Wi, Ho, Wo,
-                       tiles_x, Col2imMse{});
-  return (int)hipGetLastError();
-}
-
 template <int CQ>
 int launch_gemm(const float* in, const float* w, float* P, long long M, hipStream_t s) {
   constexpr int C = CQ * 16;
@@ -390,15 +237,4 @@ int launch_deconv3_col2im(const float* P, const float* bias, float* out, int B, 
     hipLaunchKernelGGL(deconv3_col2im_kernel<false>, dim3(tiles_x * tiles_y, B), dim3(256), 0, s, P, bias, out, Hi, Wi, Ho,
                        Wo, tiles_x, Col2imMse{});
   return (int)hipGetLastError();
-}
-
-// one launch: GEMM into LDS + col2im (+ distortion); C in {64, 128, 192}.  Returns hipErrorInvalidValue for other widths (caller falls back)
-int launch_deconv3_fused(const float* in, const float* w80, const float* bias, float* out, int B, int Hi, int Wi, int C, int Ho, int Wo,
-                         const float* x, const StepCtx* ctx, ImgSums* sums, float* gpad, int Hp, int Wp, hipStream_t s) {
-  switch (C / 16) {
-    case 4: return launch_fused<4>(in, w80, bias, out, B, Hi, Wi, Ho, Wo, x, ctx, sums, gpad, Hp, Wp, s);
-    case 8: return launch_fused<8>(in, w80, bias, out, B, Hi, Wi, Ho, Wo, x, ctx, sums, gpad, Hp, Wp, s);
-    case 12: return launch_fused<12>(in, w80, bias, out, B, Hi, Wi, Ho, Wo, x, ctx, sums, gpad, Hp, Wp, s);
-  }
-  return (int)hipErrorInvalidValue;
 }

@@ -57,9 +57,6 @@ int launch_deconv3_halo_mse(const float* in, const float* w, const float* bias, 
 int launch_deconv3_gemm(const float* in, const float* w80, float* P, int B, int Hi, int Wi, int C, hipStream_t s);
 int launch_deconv3_col2im(const float* P, const float* bias, float* out, int B, int Hi, int Wi, int Ho, int Wo,
                           const float* x, const StepCtx* ctx, ImgSums* sums, float* gpad, int Hp, int Wp, hipStream_t s);
-// ... and both as ONE launch (products of a 16 x 16 tile + halo into LDS, col2im out of LDS; C <= 192; laboratory, SGA_GS3_FUSED=1)
-int launch_deconv3_fused(const float* in, const float* w80, const float* bias, float* out, int B, int Hi, int Wi, int C, int Ho, int Wo,
-                         const float* x, const StepCtx* ctx, ImgSums* sums, float* gpad, int Hp, int Wp, hipStream_t s);
 int launch_mse(const float* x, const float* xt, const StepCtx* ctx, int B, int H, int W, int Hp,
                int Wp, ImgSums* sums, float* gpad, float* xq_out, hipStream_t s);
 

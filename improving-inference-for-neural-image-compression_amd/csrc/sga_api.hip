@@ -90,7 +90,6 @@ struct sga_handle {
   float* gs3_w80 = nullptr;      // the same layer for deconv3_gemm.hip: [80][C], row (ky*5+kx)*3 + c
   Buf p3;                        // its product matrix P [B * 8yh * 8yw][80]
   bool gs3_gemm = false;         // SGA_GS3_GEMM=1: GEMM + col2im (deconv3_gemm.hip) instead of the halo-tiled kernel (deconv3.hip)
-  bool gs3_fused = false;        // SGA_GS3_FUSED=1 (laboratory, round 6): the GEMM + col2im pair as ONE launch (products of a 16 x 16 tile + halo in LDS)
   std::vector<void*> owned;      // every hipMalloc'd block
 
   // ---- workspace ----
@@ -1010,20 +1009,15 @@ int deconv_to3(sga_handle* h, const PackedConv& pc, const float* bias, const flo
     sga_handle::ProfRec r;
     if (h->profiling) {
       r.flops = 2.0 * B * Hi * Wi * 25.0 * pc.Kc * 3.0;
-      const bool fusedk = gemm && h->gs3_fused && pc.Kc <= 192 && pc.Kc % 64 == 0;
-      const char* kn = fusedk ? "deconv3_fused" : (gemm ? "deconv3_gemm+col2im" : "deconv3_halo_kernel");
+      const char* kn = gemm ? "deconv3_gemm+col2im" : "deconv3_halo_kernel";
       if (h->profile_by_layer) snprintf(r.name, sizeof(r.name), "%s %s", h->cur_tag, kn);
       else snprintf(r.name, sizeof(r.name), "%s", kn);
       HIPCHK(h, hipEventCreate(&r.a));
       HIPCHK(h, hipEventCreate(&r.b));
       HIPCHK(h, hipEventRecord(r.a, st));
     }
-    if (gemm && h->gs3_fused && pc.Kc <= 192 && pc.Kc % 64 == 0) {
-      const bool fuse = mse_x && h->fused_mse;
-      HIPCHK(h, launch_deconv3_fused(in, h->gs3_w80, bias, out, B, Hi, Wi, pc.Kc, Ho, Wo, fuse ? mse_x : nullptr, h->ctx, h->sums,
-                                     h->gpad.p, Hp, Wp, st));
-      if (fuse) *mse_done = true;
-    } else if (gemm) {
+    if (gemm) {      // (the pair as ONE launch -- products of a 16 x 16 tile + halo in LDS -- was built in round 6, bit-equal, and measured
+                     //  77.5 us alone against 64.2, +20 us per iteration: git tag lab-r06, profiles/r06_gs3_fused_one_launch.txt)
       const bool fuse = mse_x && h->fused_mse;
       HIPCHK(h, launch_deconv3_gemm(in, h->gs3_w80, h->p3.p, B, Hi, Wi, pc.Kc, st));
       HIPCHK(h, launch_deconv3_col2im(h->p3.p, bias, out, B, Hi, Wi, Ho, Wo, fuse ? mse_x : nullptr, h->ctx, h->sums,
@@ -1617,8 +1611,6 @@ int sga_create(sga_handle** out, const sga_config* cfg, const sga_weights* w) {
       // the iteration is 30 us shorter (joint sweep, DESIGN_EXPERIMENTS.md A.7); SGA_GS3_GEMM=0 selects the halo kernel.
       const char* eg = LAB_ENV("SGA_GS3_GEMM");
       h->gs3_gemm = !(eg && eg[0] == '0');
-      eg = LAB_ENV("SGA_GS3_FUSED");
-      h->gs3_fused = eg && eg[0] == '1';
     }
     const char* e3 = LAB_ENV("SGA_GS3_GENERIC");
     h->gs3_generic = e3 && e3[0] == '1';

@@ -190,34 +190,6 @@ def test_gs3_as_gemm_plus_col2im_equals_the_halo_kernel(C, B, H, W):
     gemm.close(); halo.close()
 
 
-@pytest.mark.parametrize("C,B,H,W", [(64, 2, 64, 64), (64, 1, 50, 70), (128, 3, 37, 41), (192, 2, 256, 256), (192, 1, 200, 264)])
-def test_gs3_in_one_launch_equals_the_gemm_plus_col2im_pair(C, B, H, W):
-    """Round 6 (VERDICT r5 #4c), laboratory: the C -> 3 layer as ONE launch -- the products of a 16 x 16 tile of positions and their
-    halo formed in LDS by the GEMM kernel's MFMA sequence, summed out of LDS in the col2im kernel's order (deconv3_fused_kernel,
-    SGA_GS3_FUSED=1) -- against the shipped two-launch pair: the same products in the same order, so reconstruction, gradient image
-    and gradients are BIT-equal (the distortion SUMS are f64 sums over other workgroup partitions: equal to 1e-12), also at ragged
-    sizes and where the tile grid does not divide the image."""
-    w = sga_amd.make_synthetic_weights(C, seed=0)
-    fused = _codec_env("SGA_GS3_FUSED", "1", w, C, B, H, W)
-    pair = _codec_env("SGA_GS3_FUSED", "0", w, C, B, H, W)
-    x = np.random.RandomState(C + W).rand(B, H, W, 3).astype(np.float32)
-    y, z = pair.encode(x)
-    fused.profile_begin(); fused.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5); names = [k["name"] for k in fused.profile_end()]
-    assert any("deconv3_fused" in n for n in names), names
-    ra = fused.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
-    rb = pair.step_grads(x, y, z, 0.4, 0.01, seed=3, it=5)
-    assert float(rb["gy"].abs().max()) > 0
-    assert torch.equal(ra["gy"], rb["gy"]) and torch.equal(ra["gz"], rb["gz"])
-    assert ra["train_mse"] == pytest.approx(rb["train_mse"], rel=1e-12) and ra["rd_loss"] == pytest.approx(rb["rd_loss"], rel=1e-6)
-    (ma, xa), (mb, xb) = fused.evaluate(x, torch.round(y), torch.round(z), want_x_hat=True), \
-        pair.evaluate(x, torch.round(y), torch.round(z), want_x_hat=True)
-    assert torch.equal(xa, xb)
-    assert torch.allclose(ma[:, [0, 1, 4]], mb[:, [0, 1, 4]], rtol=1e-6)
-    a, b = fused.run(x, 0.01, its=20, seed=1), pair.run(x, 0.01, its=20, seed=1)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    fused.close(); pair.close()
-
-
 def test_results_do_not_depend_on_the_schedule(monkeypatch):
     """where the hyper branch is forked (timed per geometry in runs of >= 100 iterations), whether it is forked
     at all, and whether the step graph is replayed or launched eagerly are schedule choices -- the same kernels with the same
